@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the BSMS-GNN hot path on MI355X (contract: see the task prompt / DESIGN.md).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = BSMS_Simulator forward (warmup=False) + masked-RMSE loss + backward with every parameter
+gradient materialised (N > 1: including the RCCL gradient all-reduce), on the airfoil-like synthetic
+workload of BASELINE.json (5233-node Delaunay mesh, 5 bi-stride levels, D=128, batch 8 PER GPU, fp32),
+inputs resident in HBM.  `value` = batch-8 steps per second summed over all ranks (weak scaling).
+
+Extra objects on the JSON line (rank 0, N = 1 only):
+  roofline      the L0 edge-aggregation kernel (HBM bound), timed with HIP events on its stream
+  roofline_mfma the edge-MLP chain kernels (MFMA bound), same method
+  cpu_baseline  the CPU oracle (op-for-op restatement of the reference's PyTorch path) on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "cylinder": dict(nodes=1885, levels=4, out_dim=2, pos_dim=2, latent=128),
+    "airfoil": dict(nodes=5233, levels=5, out_dim=3, pos_dim=2, latent=128),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate
+
+
+def build_mesh(kind):
+    """Synthetic Delaunay stand-in for the dataset mesh + its bi-stride hierarchy (host, once)."""
+    from scipy.spatial import Delaunay
+    from bsms_gnn_amd.hierarchy import BistrideMultiLayerGraph, to_flat_edge
+    w = WORKLOADS[kind]
+    pts = np.random.default_rng(0).random((w["nodes"], 2))
+    cells = Delaunay(pts).simplices.astype(np.int64)
+    flat = to_flat_edge(cells, "tri")
+    _, m_es, m_ids = BistrideMultiLayerGraph(flat, w["levels"], w["nodes"], pts).get_multi_layer_graphs()
+    return pts, m_es, m_ids
+
+
+def build_workload(kind, batch, device, seed=0):
+    """Consistent-mesh batch exactly as the reference collates it (datasets/base.py:319-351 + default
+    collate): node_in [B,N,C+p+1] = [state, mesh_pos, node_type], every m_gs[l] as [B,2,E_l]."""
+    w = WORKLOADS[kind]
+    pts, m_es, m_ids = build_mesh(kind)
+    n, c = w["nodes"], w["out_dim"]
+    gen = torch.Generator().manual_seed(seed)
+    state = torch.randn(batch, n, c, generator=gen)
+    target = torch.randn(batch, n, c, generator=gen)
+    pos = torch.tensor(pts, dtype=torch.float32).unsqueeze(0).repeat(batch, 1, 1)
+    node_in = torch.cat([state, pos, torch.zeros(batch, n, 1)], -1)
+    mask = torch.ones(batch, n, 1)
+    gs = [torch.tensor(e, dtype=torch.int64).unsqueeze(0).repeat(batch, 1, 1) for e in m_es]
+    ids = [torch.tensor(i, dtype=torch.int64).unsqueeze(0).repeat(batch, 1) for i in m_ids]
+    mv = lambda t: t.to(device)
+    return dict(node_in=mv(node_in), target=mv(target), mask=mv(mask), m_gs=[mv(g) for g in gs], m_ids=[mv(i) for i in ids],
+                levels=[(n if l == 0 else len(m_ids[l - 1]), m_es[l].shape[1]) for l in range(len(m_es))], cfg=w)
+
+
+def make_cfg(w):
+    from types import SimpleNamespace
+    return SimpleNamespace(out_dim=w["out_dim"], latent_dim=w["latent"], hidden_layer=3, unet_depth=w["levels"],
+                           pos_dim=w["pos_dim"], consistent_mesh=True, accumulation_steps=0)
+
+
+def data_tuple(wl):
+    return (wl["node_in"], wl["target"], wl["mask"], wl["m_gs"], wl["m_ids"])
+
+
+def cpu_baseline(kind, batch, steps=2):
+    """The oracle (CPU restatement of the reference path) on the host cores, same workload."""
+    from oracle import bsms_oracle as ro
+    torch.set_num_threads(os.cpu_count() or 1)
+    wl = build_workload(kind, batch, "cpu")
+    torch.manual_seed(0)
+    sim = ro.BSMS_Simulator(make_cfg(wl["cfg"]))
+    data = data_tuple(wl)
+    sim(data, True, True)
+    best = float("inf")
+    for it in range(steps + 1):  # first one is the warm-up
+        sim.zero_grad(set_to_none=True)
+        t0 = time.perf_counter()
+        loss = ro.masked_rmse(sim(data, True, False), wl["target"], wl["mask"])
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = min(best, dt)
+    return {"value": 1.0 / best, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{kind}-like B={batch} fwd+loss+bwd, 1 warm-up + best of {steps} steps, fp32, torch CPU {torch.__version__}",
+            "ms_per_step": best * 1e3}
+
+
+def time_kernel(fn, iters=50, warm=5):
+    """Average duration (ms) of `fn`'s launches with HIP events on the launching (current) stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def roofline_objects(wl, batch):
+    """HBM roofline of the L0 edge aggregation and MFMA roofline of the L0 edge-MLP forward chain."""
+    import ctypes as C
+    import bsms_gnn_amd as eng
+    from bsms_gnn_amd import _abi
+    from bsms_gnn_amd.ops import _stream
+    n0, e0 = wl["levels"][0]
+    D = wl["cfg"]["latent"]
+    g0 = wl["m_gs"][0][0]
+    plan = eng.plan_for(g0, n0)
+    msg = torch.randn(batch, e0, D, device="cuda")
+    out = torch.empty(batch, n0, D, device="cuda")
+    L = _abi.lib()
+    agg = lambda: _abi.check(L.bsms_segment_sum_fwd(plan.handle, msg.data_ptr(), batch, D, 1, out.data_ptr(), _stream()), "segment_sum")
+    ms = time_kernel(agg)
+    s = 4
+    algo = batch * e0 * D * s + batch * n0 * D * s + 4 * (n0 + 1) + 4 * e0
+    roof = {"kernel": "k_rowsum_v4<32,false,false> (L0 edge aggregation, bsms_segment_sum_fwd plan order)",
+            "bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": algo, "avg_us": ms * 1e3}
+    # edge-MLP forward through a GMP at L0: flops of the three D x D Linears per edge row
+    gmp = eng.GMP(D, 3, wl["cfg"]["pos_dim"]).cuda()
+    x = torch.randn(batch, n0, D, device="cuda")
+    pos = wl["node_in"][..., wl["cfg"]["out_dim"]: wl["cfg"]["out_dim"] + wl["cfg"]["pos_dim"]].contiguous()
+    with torch.no_grad():
+        msf = time_kernel(lambda: gmp(x, g0, pos, plan=plan), iters=10, warm=2)
+    p = wl["cfg"]["pos_dim"]
+    flops = 2 * batch * (e0 * (3 * D * D) + n0 * (2 * D * D + 2 * D * D + 3 * D * D))  # as executed (layer 0 hoisted to nodes)
+    mf = {"kernel": "GMP forward at L0 (prepack + proj + k_chain_fwd edge/node + aggregation)", "bound": "mfma",
+          "achieved": flops / (msf * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+          "frac": flops / (msf * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "flops": flops, "avg_us": msf * 1e3}
+    return roof, mf
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="airfoil", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=8, help="batch per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the BSMS engine has no CPU path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import bsms_gnn_amd as eng
+    wl = build_workload(args.workload, args.batch, "cuda", seed=rank)   # each rank its own samples of the shared mesh
+    torch.manual_seed(0)
+    sim = eng.BSMS_Simulator(make_cfg(wl["cfg"])).cuda()
+    data = data_tuple(wl)
+    sim(data, True, True)                                                 # one normaliser accumulation
+    dp = eng.DataParallel(sim)
+    dp.sync_normalizers()
+
+    def step():
+        return dp.step_loss_backward(data, True)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        n_params = sum(p.numel() for p in sim.parameters() if p.requires_grad)
+        line = {
+            "metric": "rollout steps/sec (1-step fwd+bwd) on airfoil mesh, batch=8",
+            "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-like Delaunay mesh, {wl['cfg']['nodes']} nodes, "
+                                   f"{wl['cfg']['levels']} bi-stride levels, D={wl['cfg']['latent']}, hidden_layer=3, "
+                                   f"batch {args.batch} per GPU (global {args.batch * world}), consistent mesh",
+                       "levels_N_E": wl["levels"], "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "trainable_params": n_params, "loss": float(loss)},
+        }
+        if world == 1 and not args.no_roofline:
+            line["roofline"], line["roofline_mfma"] = roofline_objects(wl, args.batch)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.batch)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+// MLP "chain" kernels for gfx950: the dense per-edge / per-node MLPs of the BSMS path on f32 MFMA.
+//
+// Orientation.  Every Linear y = x W^T is computed TRANSPOSED, Y^T = W X^T, with
+// v_mfma_f32_32x32x2_f32: the A operand is a weight fragment (rows = output features), the B operand
+// an activation fragment (columns = rows of x, i.e. edges / nodes).  Each wave owns 32 rows of x:
+// lane l <-> row (l & 31), half hh = l >> 5.  The 32x32 result block leaves a lane holding, for ITS
+// row, output features  f = 32 t + (r & 3) + 8 (r >> 2) + 4 hh  (r = accumulator register 0..15).
+// The MFMA sums over k in {0,1} supplied by the two half-waves; we are free to decide WHICH feature
+// each (step s, half hh) stands for, as long as A and B agree.  Choosing
+//          k(s, hh) = 32 kb + (s & 3) + 8 (s >> 2) + 4 hh
+// makes the accumulator layout of one layer exactly the B-operand layout of the next: activations
+// never leave registers between layers -- no LDS round trip, no HBM traffic.  LayerNorm over a row
+// is 64 in-lane values + one cross-half exchange.
+//
+// Weights are re-laid out once per call ("prepack") into fragment order
+//          Wp[kb][t][s4][lane][c]   (c = s & 3, s4 = s >> 2)      value = W[32 t + (lane & 31)][k(s, lane >> 5)]
+// so that a K-block (32 input features x all outputs; 16 KB at D = 128) is one contiguous chunk: the
+// workgroup streams chunks L2 -> LDS through a 2-deep ring (one barrier per chunk) and every wave
+// reads its A fragments with conflict-free, lane-linear ds_read_b128.  f32 MFMA needs only
+// 16 B/clk/CU of operand bandwidth in this scheme, so the kernels are MFMA-issue bound by design.
+#pragma once
+#include "common.h"
+
+namespace bsms {
+
+constexpr int kMaxStages = 8;   // max Linear layers per MLP handled by one chain launch
+constexpr int kTileRows = 128;  // rows of x per workgroup (4 waves x 32)
+
+enum ChainIn { IN_ROWS = 0, IN_ROWS2 = 1, IN_SMALL = 2, IN_EDGE = 3 };
+enum ChainOut { OUT_LN = 0, OUT_PLAIN = 1, OUT_SMALL = 2 };
+enum GradIn { G_ROWS_LN = 0, G_EDGE_LN = 1, G_SMALL = 2 };
+enum GradFirst { F_NONE = 0, F_HEADS1 = 1, F_HEADS2 = 2 };
+
+struct ChainFwdArgs {
+  int64_t R;  // rows
+  // ---- input stage
+  const float* x;    // IN_ROWS/IN_ROWS2: [R,D]; IN_SMALL: [R,K0]
+  const float* x2;   // IN_ROWS2: second source [R,D]
+  int K0;            // IN_SMALL: input width; IN_EDGE: p+1
+  const float* w0t;  // IN_SMALL: W0^T [K0][D]; IN_EDGE: fiber weights^T [p+1][D]
+  const float* bias_in;  // IN_SMALL: b0 [D]
+  float* store_in;   // IN_SMALL/IN_EDGE: activation after the input stage [R,D] (nullable)
+  const int32_t *src, *dst;  // IN_EDGE: plan-order endpoints
+  int32_t E, N;
+  const float *Ps, *Pd;      // IN_EDGE: per-node pre-projections [B*N, D]
+  const float* pos;          // IN_EDGE
+  int64_t pos_bstride;
+  int p;
+  // ---- MFMA stages
+  int nstage;
+  const float4* wp[kMaxStages];
+  const float4* wp0b;  // IN_ROWS2: pack for x2 in stage 0
+  const float* bias[kMaxStages];
+  float* store[kMaxStages];  // post-ReLU activation of stage l (nullable)
+  // ---- output
+  float* y;           // OUT_LN / OUT_PLAIN: [R,D]; OUT_SMALL: [R,C]
+  float* yln;         // OUT_LN: normalised output before the residual (nullable)
+  float* rstd;        // OUT_LN: [R] (nullable)
+  const float* resid; // OUT_LN: residual rows added to y (nullable)
+  int accumulate;     // OUT_PLAIN: y += result
+  const float* wout;  // OUT_SMALL: [C][D]
+  const float* bout;  // OUT_SMALL: [C]
+  int C;
+};
+
+struct ChainBwdArgs {
+  int64_t R;
+  const float* dy;    // G_ROWS_LN: [R,D]; G_EDGE_LN: [B*N,D] node gradient gathered by dst; G_SMALL: [R,C]
+  const float* yln;   // LN cases: normalised forward output [R,D]
+  const float* rstd;  // LN cases: [R]
+  const int32_t* dst; // G_EDGE_LN
+  int32_t E, N;
+  const float* wout;  // G_SMALL: [C][D]
+  int C;
+  const float* mask_in;  // G_SMALL: activation masking the VALU-produced gradient
+  int nstage;
+  const float4* wpt[kMaxStages];  // transposed packs, execution order (top layer first)
+  const float* mask[kMaxStages];  // activation whose sign masks the OUTPUT of stage k
+  float* gstore[kMaxStages + 1];  // [0]: gradient entering stage 0; [k+1]: output of stage k (nullable)
+  // ---- first-layer input gradient
+  const float4 *wh0, *wh1;
+  float *dx, *dx2;
+  const float* dres;  // added to dx (residual branch), nullable
+};
+
+// prepack table ---------------------------------------------------------------------------------
+enum PackKind { PACK_FRAG = 0, PACK_FRAG_T = 1, PACK_TRANSPOSE = 2 };
+struct PackDesc {
+  const float* W;  // row-major, leading dimension ld
+  float* dst;
+  int ld, row0, col0;
+  int N, K;  // logical matrix M[n][k], n < N (outputs), k < K (reduction)
+  int kind;  // FRAG: M[n][k] = W[row0+n][col0+k]; FRAG_T: M[n][k] = W[row0+k][col0+n];
+             // TRANSPOSE: dst[k*N+n] = W[row0+n][col0+k] (plain, for the small VALU layers)
+};
+constexpr int kMaxPack = 40;
+struct PackTable {
+  int n;
+  PackDesc d[kMaxPack];
+};
+int launch_prepack(const PackTable& t, hipStream_t s);
+
+int launch_chain_fwd(int D, int in_mode, int out_mode, const ChainFwdArgs& a, hipStream_t s);
+int launch_chain_bwd(int D, int gin_mode, int first_mode, const ChainBwdArgs& a, hipStream_t s);
+
+// weight gradients ------------------------------------------------------------------------------
+struct WgradJob {
+  const float* G;  // [R, ldg] gradient w.r.t. the Linear's output
+  const float* A;  // [R, lda] the Linear's input
+  float* dW;       // dW[n*ldw + col0 + k] = sum_r G[r][n] * A[r][k]   (n,k < D)
+  float* db;       // db[n] = sum_r G[r][n]   (nullable)
+  int64_t R;
+  int ldg, lda, ldw, col0;
+};
+constexpr int kMaxWgradJobs = 20;
+size_t wgrad_work_bytes(int D, int njobs);
+int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t s);
+
+// small-side weight gradients: out[s*os + f*of] = sum_r G[r][f] * S[r][s],  s < S (<= 8)
+struct SmallWgradArgs {
+  const float* G;  // [R,D]
+  const float* S;  // [R,S] (null when fiber mode)
+  int S_cols;
+  // fiber mode: S[r] = [pos_i - pos_j, |pos_i - pos_j|] recomputed from the plan (edge layer 0)
+  const int32_t *src, *dst;
+  int32_t E, N;
+  const float* pos;
+  int64_t pos_bstride;
+  int p;
+  float* out;  // element (s,f) at out[s*os + f*of]
+  int64_t os, of;
+  float* colsum;  // optional: colsum[f] = sum_r G[r][f]
+  float* colsum_S;  // optional: colsum_S[s] = sum_r S[r][s]  (decoder output bias)
+  int64_t R;
+  int D;
+};
+size_t small_wgrad_work_bytes(int D);
+int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s);
+
+// from rowsum.hip
+int rowsum_plan_order(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
+int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
+
+}  // namespace bsms

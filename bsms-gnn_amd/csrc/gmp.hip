@@ -1,0 +1,456 @@
+// Host orchestration of the two coarse C-ABI entries: a whole MLP (encoder / decoder) and a whole GMP
+// block (ops/basic.py:26-98), forward and backward, as sequences of the chain / rowsum / wgrad kernels.
+//
+// GMP forward (H = hidden layers):
+//   prepack            all weight matrices of the block -> MFMA fragment order (one launch; kept for bwd)
+//   proj  x2           Ps = x Wi^T + b0,  Pd = x Wj^T         (the first edge Linear split by linearity:
+//                      W0 [fiber | x_i | x_j] = Wf fiber + Wi x_i + Wj x_j, so 2 D^2 MACs per NODE
+//                      instead of per EDGE; ops/basic.py:90 concatenation order [fiber, x_i, x_j])
+//   edge chain         relu(Ps[i] + Pd[j] + Wf fiber) -> H-1 x (Linear, ReLU) -> Linear -> LayerNorm
+//   segment sum        aggr[b,n] = sum of messages into n (dst-sorted CSR, no atomics)
+//   node chain         [x, aggr] -> MLP -> LayerNorm -> + x
+// GMP backward mirrors it: node chain bwd -> edge chain bwd -> segment sums of the edge gradient by
+// source and by target -> all weight gradients in one batched split-K launch -> input gradient.
+#include "chain.h"
+
+using namespace bsms;
+
+namespace {
+
+struct Carver {  // identical walk for size queries (base == nullptr) and real buffers
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base(reinterpret_cast<char*>(b)) {}
+  float* take(size_t nfloat) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += align_up(nfloat * sizeof(float));
+    return p;
+  }
+  char* take_bytes(size_t n) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(n);
+    return p;
+  }
+};
+
+bool supported_D(int64_t D) { return D == 32 || D == 64 || D == 128 || D == 256; }
+
+void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, int K, int kind, float* dst) {
+  PackDesc& d = t.d[t.n++];
+  d.W = W; d.dst = dst; d.ld = ld; d.row0 = row0; d.col0 = col0; d.N = N; d.K = K; d.kind = kind;
+}
+
+// ================================================================================== GMP layout
+struct GmpSaved {
+  float *e_act[kMaxStages], *e_y, *e_rstd, *aggr;
+  float *n_act[kMaxStages], *n_yln, *n_rstd;
+  // packs (fragment order)
+  float *e_wi, *e_wj, *e_wft, *e_w[kMaxStages], *e_wt[kMaxStages], *e_wit, *e_wjt;
+  float *n_w0x, *n_w0a, *n_w[kMaxStages], *n_wt[kMaxStages], *n_w0xt, *n_w0at;
+  size_t bytes;
+};
+GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H) {
+  Carver c(base);
+  GmpSaved s{};
+  const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = size_t(D) * D;
+  for (int l = 0; l < H; ++l) s.e_act[l] = c.take(re * D);
+  s.e_y = c.take(re * D);
+  s.e_rstd = c.take(re);
+  s.aggr = c.take(rn * D);
+  for (int l = 0; l < H; ++l) s.n_act[l] = c.take(rn * D);
+  s.n_yln = c.take(rn * D);
+  s.n_rstd = c.take(rn);
+  s.e_wi = c.take(dd); s.e_wj = c.take(dd); s.e_wft = c.take(size_t(8) * D);
+  s.e_wit = c.take(dd); s.e_wjt = c.take(dd);
+  for (int l = 1; l <= H; ++l) { s.e_w[l] = c.take(dd); s.e_wt[l] = c.take(dd); }
+  s.n_w0x = c.take(dd); s.n_w0a = c.take(dd); s.n_w0xt = c.take(dd); s.n_w0at = c.take(dd);
+  for (int l = 1; l <= H; ++l) { s.n_w[l] = c.take(dd); s.n_wt[l] = c.take(dd); }
+  s.bytes = c.off;
+  return s;
+}
+
+struct GmpWork {
+  float *Ps, *Pd;                    // fwd
+  float *gN[kMaxStages + 1], *daggr; // bwd
+  float *gE[kMaxStages + 1], *dPs, *dPd;
+  char *wg, *sw;
+  size_t bytes;
+};
+GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H) {
+  Carver c(base);
+  GmpWork w{};
+  const size_t re = size_t(B) * E, rn = size_t(B) * N;
+  w.Ps = c.take(rn * D); w.Pd = c.take(rn * D);
+  w.dPs = w.Ps; w.dPd = w.Pd;  // the backward reuses the two projection buffers for their gradients
+  for (int l = 0; l <= H; ++l) w.gN[l] = c.take(rn * D);
+  w.daggr = c.take(rn * D);
+  for (int l = 0; l <= H; ++l) w.gE[l] = c.take(re * D);
+  w.wg = c.take_bytes(wgrad_work_bytes((int)D, 0));
+  w.sw = c.take_bytes(small_wgrad_work_bytes((int)D));
+  w.bytes = c.off;
+  return w;
+}
+
+int check_gmp(const bsms_plan_t* plan, int64_t B, int64_t D, int64_t p, int H, const char* who) {
+  BSMS_REQUIRE(plan != nullptr, BSMS_E_INVALID_ARG, "%s: plan is null", who);
+  BSMS_REQUIRE(supported_D(D), BSMS_E_UNSUPPORTED, "%s: latent width D=%lld not supported (32, 64, 128, 256)", who, (long long)D);
+  BSMS_REQUIRE(p >= 1 && p <= 7, BSMS_E_UNSUPPORTED, "%s: pos_dim=%lld (1..7)", who, (long long)p);
+  BSMS_REQUIRE(H >= 1 && H < kMaxStages, BSMS_E_UNSUPPORTED, "%s: hidden=%d (1..%d)", who, H, kMaxStages - 1);
+  BSMS_REQUIRE(B >= 0, BSMS_E_SHAPE, "%s: B=%lld", who, (long long)B);
+  BSMS_REQUIRE(B * std::max(plan->E, plan->N) * D < (int64_t(1) << 40), BSMS_E_SHAPE, "%s: tensor too large", who);
+  return BSMS_OK;
+}
+
+}  // namespace
+
+// =================================================================================== GMP entries
+extern "C" size_t bsms_gmp_saved_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden) {
+  if (hidden < 1 || hidden >= kMaxStages) return 0;
+  return carve_gmp_saved(nullptr, B, N, E, D, hidden).bytes;
+}
+extern "C" size_t bsms_gmp_work_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden) {
+  if (hidden < 1 || hidden >= kMaxStages) return 0;
+  return carve_gmp_work(nullptr, B, N, E, D, hidden).bytes;
+}
+
+extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
+                            int64_t pos_bstride, int H, const float* const* params, float* out, void* saved,
+                            void* work, bsms_stream_t stream) {
+  int rc = check_gmp(plan, B, D, p, H, "gmp_fwd");
+  if (rc) return rc;
+  BSMS_REQUIRE(x && pos && params && out && saved && work, BSMS_E_INVALID_ARG, "gmp_fwd: null argument");
+  hipStream_t s = as_stream(stream);
+  const int64_t N = plan->N, E = plan->E;
+  const int nl = H + 1;
+  const float* const* pn = params;            // mlp_node: W_l = pn[2l], b_l = pn[2l+1]
+  const float* const* pe = params + 2 * nl;   // mlp_edge
+  const int ldE0 = int(2 * D + p + 1);
+  GmpSaved sv = carve_gmp_saved(saved, B, N, E, D, H);
+  GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
+
+  PackTable t{};
+  add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG, sv.e_wi);
+  add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG, sv.e_wj);
+  add_pack(t, pe[0], ldE0, 0, 0, (int)D, int(p + 1), PACK_TRANSPOSE, sv.e_wft);
+  add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG_T, sv.e_wit);
+  add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG_T, sv.e_wjt);
+  for (int l = 1; l <= H; ++l) {
+    add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.e_w[l]);
+    add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]);
+  }
+  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x);
+  add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG, sv.n_w0a);
+  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_w0xt);
+  add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG_T, sv.n_w0at);
+  for (int l = 1; l <= H; ++l) {
+    add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w[l]);
+    add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_wt[l]);
+  }
+  if ((rc = launch_prepack(t, s))) return rc;
+
+  // node pre-projections
+  {
+    ChainFwdArgs a{};
+    a.R = B * N; a.x = x; a.nstage = 1;
+    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wi); a.bias[0] = pe[1]; a.y = wk.Ps;
+    if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN, a, s))) return rc;
+    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wj); a.bias[0] = nullptr; a.y = wk.Pd;
+    if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN, a, s))) return rc;
+  }
+  // edge MLP + LayerNorm
+  {
+    ChainFwdArgs a{};
+    a.R = B * E; a.K0 = int(p + 1); a.w0t = sv.e_wft; a.store_in = sv.e_act[0];
+    a.src = plan->src; a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
+    a.Ps = wk.Ps; a.Pd = wk.Pd; a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p;
+    a.nstage = H;
+    for (int st = 0; st < H; ++st) {
+      a.wp[st] = reinterpret_cast<const float4*>(sv.e_w[st + 1]);
+      a.bias[st] = pe[2 * (st + 1) + 1];
+      a.store[st] = (st < H - 1) ? sv.e_act[st + 1] : nullptr;
+    }
+    a.y = sv.e_y; a.rstd = sv.e_rstd;
+    if ((rc = launch_chain_fwd((int)D, IN_EDGE, OUT_LN, a, s))) return rc;
+  }
+  // aggregation (scatter_sum over targets, ops/basic.py:94)
+  if ((rc = rowsum_plan_order(plan, sv.e_y, B, D, sv.aggr, s))) return rc;
+  // node MLP + LayerNorm + residual
+  {
+    ChainFwdArgs a{};
+    a.R = B * N; a.x = x; a.x2 = sv.aggr; a.nstage = H + 1;
+    a.wp[0] = reinterpret_cast<const float4*>(sv.n_w0x);
+    a.wp0b = reinterpret_cast<const float4*>(sv.n_w0a);
+    a.bias[0] = pn[1]; a.store[0] = sv.n_act[0];
+    for (int st = 1; st <= H; ++st) {
+      a.wp[st] = reinterpret_cast<const float4*>(sv.n_w[st]);
+      a.bias[st] = pn[2 * st + 1];
+      a.store[st] = (st < H) ? sv.n_act[st] : nullptr;
+    }
+    a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x;
+    if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_LN, a, s))) return rc;
+  }
+  return BSMS_OK;
+}
+
+extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float* pos, const float* grad_out, int64_t B,
+                            int64_t D, int64_t p, int64_t pos_bstride, int H, const float* const* params,
+                            const void* saved, void* work, float* grad_x, float* const* grads, bsms_stream_t stream) {
+  int rc = check_gmp(plan, B, D, p, H, "gmp_bwd");
+  if (rc) return rc;
+  BSMS_REQUIRE(x && pos && grad_out && params && saved && work && grad_x && grads, BSMS_E_INVALID_ARG,
+               "gmp_bwd: null argument");
+  hipStream_t s = as_stream(stream);
+  const int64_t N = plan->N, E = plan->E;
+  const int nl = H + 1;
+  float* const* gn = grads;
+  float* const* ge = grads + 2 * nl;
+  const int ldE0 = int(2 * D + p + 1);
+  GmpSaved sv = carve_gmp_saved(const_cast<void*>(saved), B, N, E, D, H);
+  GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
+
+  // node MLP backward: grad_x = grad_out (residual) + g0 W0x ; daggr = g0 W0a
+  {
+    ChainBwdArgs a{};
+    a.R = B * N; a.dy = grad_out; a.yln = sv.n_yln; a.rstd = sv.n_rstd;
+    a.nstage = H;
+    a.gstore[0] = wk.gN[H];
+    for (int k = 0; k < H; ++k) {
+      a.wpt[k] = reinterpret_cast<const float4*>(sv.n_wt[H - k]);
+      a.mask[k] = sv.n_act[H - k - 1];
+      a.gstore[k + 1] = wk.gN[H - k - 1];
+    }
+    a.wh0 = reinterpret_cast<const float4*>(sv.n_w0xt);
+    a.wh1 = reinterpret_cast<const float4*>(sv.n_w0at);
+    a.dx = grad_x; a.dx2 = wk.daggr; a.dres = grad_out;
+    if ((rc = launch_chain_bwd((int)D, G_ROWS_LN, F_HEADS2, a, s))) return rc;
+  }
+  // edge MLP backward (gradient of the aggregation = gather by target)
+  {
+    ChainBwdArgs a{};
+    a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd;
+    a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
+    a.nstage = H;
+    a.gstore[0] = wk.gE[H];
+    for (int k = 0; k < H; ++k) {
+      a.wpt[k] = reinterpret_cast<const float4*>(sv.e_wt[H - k]);
+      a.mask[k] = sv.e_act[H - k - 1];
+      a.gstore[k + 1] = wk.gE[H - k - 1];
+    }
+    if ((rc = launch_chain_bwd((int)D, G_EDGE_LN, F_NONE, a, s))) return rc;
+  }
+  // gradient of the first edge Linear w.r.t. the two per-node projections
+  if ((rc = rowsum_by_source(plan, wk.gE[0], B, D, wk.dPs, s))) return rc;
+  if ((rc = rowsum_plan_order(plan, wk.gE[0], B, D, wk.dPd, s))) return rc;
+  // fiber columns of W0_edge and its bias
+  {
+    SmallWgradArgs a{};
+    a.G = wk.gE[0]; a.S = nullptr; a.S_cols = int(p + 1);
+    a.src = plan->src; a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
+    a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p;
+    a.out = ge[0]; a.os = 1; a.of = ldE0; a.colsum = ge[1];
+    a.R = B * E; a.D = (int)D;
+    if ((rc = launch_small_wgrad(a, wk.sw, s))) return rc;
+  }
+  // every D x D weight gradient of the block in one batched split-K launch
+  {
+    WgradJob jobs[kMaxWgradJobs];
+    int nj = 0;
+    auto add = [&](const float* G, const float* A, float* dW, float* db, int64_t R, int ldw, int col0) {
+      WgradJob& j = jobs[nj++];
+      j.G = G; j.A = A; j.dW = dW; j.db = db; j.R = R; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldw; j.col0 = col0;
+    };
+    for (int l = 1; l <= H; ++l) add(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0);
+    add(wk.dPs, x, ge[0], nullptr, B * N, ldE0, int(p + 1));
+    add(wk.dPd, x, ge[0], nullptr, B * N, ldE0, int(p + 1 + D));
+    for (int l = 1; l <= H; ++l) add(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0);
+    add(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0);
+    add(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D);
+    if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, s))) return rc;
+  }
+  // grad_x += dPs Wi + dPd Wj
+  {
+    ChainFwdArgs a{};
+    a.R = B * N; a.x = wk.dPs; a.x2 = wk.dPd; a.nstage = 1;
+    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wit);
+    a.wp0b = reinterpret_cast<const float4*>(sv.e_wjt);
+    a.y = grad_x; a.accumulate = 1;
+    if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_PLAIN, a, s))) return rc;
+  }
+  return BSMS_OK;
+}
+
+// =================================================================================== MLP entries
+namespace {
+
+enum MlpKind { MLP_SMALL_LN, MLP_ROWS_LN, MLP_ROWS_SMALL, MLP_BAD };
+MlpKind mlp_kind(int64_t in_dim, int64_t D, int64_t out_dim, int layer_norm) {
+  const bool in_small = in_dim >= 1 && in_dim <= 8 && in_dim != D, in_rows = in_dim == D;
+  if (layer_norm && out_dim == D) return in_small ? MLP_SMALL_LN : (in_rows ? MLP_ROWS_LN : MLP_BAD);
+  if (!layer_norm && out_dim >= 1 && out_dim <= 8 && in_rows) return MLP_ROWS_SMALL;
+  return MLP_BAD;
+}
+
+struct MlpSaved {
+  float *act[kMaxStages], *yln, *rstd;
+  float *w[kMaxStages + 1], *wt[kMaxStages + 1], *w0t;
+  size_t bytes;
+};
+MlpSaved carve_mlp_saved(void* base, int64_t R, int64_t D, int H) {
+  Carver c(base);
+  MlpSaved s{};
+  for (int l = 0; l < H; ++l) s.act[l] = c.take(size_t(R) * D);
+  s.yln = c.take(size_t(R) * D);
+  s.rstd = c.take(size_t(R));
+  for (int l = 0; l <= H; ++l) { s.w[l] = c.take(size_t(D) * D); s.wt[l] = c.take(size_t(D) * D); }
+  s.w0t = c.take(size_t(16) * D);
+  s.bytes = c.off;
+  return s;
+}
+struct MlpWork {
+  float* g[kMaxStages + 1];
+  char *wg, *sw;
+  size_t bytes;
+};
+MlpWork carve_mlp_work(void* base, int64_t R, int64_t D, int H) {
+  Carver c(base);
+  MlpWork w{};
+  for (int l = 0; l <= H; ++l) w.g[l] = c.take(size_t(R) * D);
+  w.wg = c.take_bytes(wgrad_work_bytes((int)D, 0));
+  w.sw = c.take_bytes(small_wgrad_work_bytes((int)D));
+  w.bytes = c.off;
+  return w;
+}
+
+int check_mlp(int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int H, int layer_norm, const char* who) {
+  BSMS_REQUIRE(supported_D(D), BSMS_E_UNSUPPORTED, "%s: latent width D=%lld not supported (32, 64, 128, 256)", who, (long long)D);
+  BSMS_REQUIRE(H >= 1 && H < kMaxStages, BSMS_E_UNSUPPORTED, "%s: hidden=%d (1..%d)", who, H, kMaxStages - 1);
+  BSMS_REQUIRE(R >= 0, BSMS_E_SHAPE, "%s: R=%lld", who, (long long)R);
+  BSMS_REQUIRE(mlp_kind(in_dim, D, out_dim, layer_norm) != MLP_BAD, BSMS_E_UNSUPPORTED,
+               "%s: MLP shape in=%lld D=%lld out=%lld ln=%d not supported", who, (long long)in_dim, (long long)D,
+               (long long)out_dim, layer_norm);
+  return BSMS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t bsms_mlp_saved_bytes(int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int hidden) {
+  (void)in_dim; (void)out_dim;
+  if (hidden < 1 || hidden >= kMaxStages) return 0;
+  return carve_mlp_saved(nullptr, R, D, hidden).bytes;
+}
+extern "C" size_t bsms_mlp_work_bytes(int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int hidden) {
+  (void)in_dim; (void)out_dim;
+  if (hidden < 1 || hidden >= kMaxStages) return 0;
+  return carve_mlp_work(nullptr, R, D, hidden).bytes;
+}
+
+extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int H, int layer_norm,
+                            const float* const* params, float* y, void* saved, void* work, bsms_stream_t stream) {
+  int rc = check_mlp(R, in_dim, D, out_dim, H, layer_norm, "mlp_fwd");
+  if (rc) return rc;
+  BSMS_REQUIRE((x && y && saved) || R == 0, BSMS_E_INVALID_ARG, "mlp_fwd: null argument");
+  BSMS_REQUIRE(params != nullptr, BSMS_E_INVALID_ARG, "mlp_fwd: params is null");
+  (void)work;
+  hipStream_t s = as_stream(stream);
+  const MlpKind kind = mlp_kind(in_dim, D, out_dim, layer_norm);
+  MlpSaved sv = carve_mlp_saved(saved, R, D, H);
+
+  PackTable t{};
+  const int lfirst = (kind == MLP_SMALL_LN) ? 1 : 0;          // first Linear that runs on the MFMA
+  const int llast = (kind == MLP_ROWS_SMALL) ? H - 1 : H;     // last one
+  if (kind == MLP_SMALL_LN) add_pack(t, params[0], (int)in_dim, 0, 0, (int)D, (int)in_dim, PACK_TRANSPOSE, sv.w0t);
+  for (int l = lfirst; l <= llast; ++l) {
+    add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.w[l]);
+    add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.wt[l]);
+  }
+  if ((rc = launch_prepack(t, s))) return rc;
+
+  ChainFwdArgs a{};
+  a.R = R; a.x = x;
+  int st = 0;
+  if (kind == MLP_SMALL_LN) {
+    a.K0 = (int)in_dim; a.w0t = sv.w0t; a.bias_in = params[1]; a.store_in = sv.act[0];
+  }
+  for (int l = lfirst; l <= llast; ++l, ++st) {
+    a.wp[st] = reinterpret_cast<const float4*>(sv.w[l]);
+    a.bias[st] = params[2 * l + 1];
+    a.store[st] = (l < H) ? sv.act[l] : nullptr;
+  }
+  a.nstage = st;
+  a.y = y;
+  if (kind == MLP_ROWS_SMALL) {
+    a.wout = params[2 * H]; a.bout = params[2 * H + 1]; a.C = (int)out_dim;
+    return launch_chain_fwd((int)D, IN_ROWS, OUT_SMALL, a, s);
+  }
+  a.yln = sv.yln; a.rstd = sv.rstd;
+  return launch_chain_fwd((int)D, kind == MLP_SMALL_LN ? IN_SMALL : IN_ROWS, OUT_LN, a, s);
+}
+
+extern "C" int bsms_mlp_bwd(const float* x, const float* grad_y, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim,
+                            int H, int layer_norm, const float* const* params, const void* saved, void* work,
+                            float* grad_x, float* const* grads, bsms_stream_t stream) {
+  int rc = check_mlp(R, in_dim, D, out_dim, H, layer_norm, "mlp_bwd");
+  if (rc) return rc;
+  BSMS_REQUIRE(params && grads && saved && work, BSMS_E_INVALID_ARG, "mlp_bwd: null argument");
+  BSMS_REQUIRE((x && grad_y) || R == 0, BSMS_E_INVALID_ARG, "mlp_bwd: null tensor");
+  hipStream_t s = as_stream(stream);
+  const MlpKind kind = mlp_kind(in_dim, D, out_dim, layer_norm);
+  BSMS_REQUIRE(!(kind == MLP_SMALL_LN && grad_x), BSMS_E_UNSUPPORTED,
+               "mlp_bwd: input gradient of a narrow-input MLP is not implemented (pass grad_x = NULL)");
+  BSMS_REQUIRE(kind == MLP_SMALL_LN || grad_x, BSMS_E_INVALID_ARG, "mlp_bwd: grad_x is null");
+  MlpSaved sv = carve_mlp_saved(const_cast<void*>(saved), R, D, H);
+  MlpWork wk = carve_mlp_work(work, R, D, H);
+
+  // g[l] = gradient w.r.t. the output of Linear_l (pre-activation)
+  ChainBwdArgs a{};
+  a.R = R; a.dy = grad_y;
+  int top;  // Linear index whose output gradient enters the chain
+  if (kind == MLP_ROWS_SMALL) {
+    a.wout = params[2 * H]; a.C = (int)out_dim; a.mask_in = sv.act[H - 1];
+    top = H - 1;
+  } else {
+    a.yln = sv.yln; a.rstd = sv.rstd;
+    top = H;
+  }
+  const int bottom = (kind == MLP_SMALL_LN) ? 1 : 1;  // dgrad stages run Linear_top .. Linear_1
+  a.gstore[0] = wk.g[top];
+  int k = 0;
+  for (int l = top; l >= bottom; --l, ++k) {
+    a.wpt[k] = reinterpret_cast<const float4*>(sv.wt[l]);
+    a.mask[k] = sv.act[l - 1];
+    a.gstore[k + 1] = wk.g[l - 1];
+  }
+  a.nstage = k;
+  if (kind == MLP_SMALL_LN) {
+    rc = launch_chain_bwd((int)D, G_ROWS_LN, F_NONE, a, s);
+  } else {
+    a.wh0 = reinterpret_cast<const float4*>(sv.wt[0]);
+    a.dx = grad_x;
+    rc = launch_chain_bwd((int)D, kind == MLP_ROWS_SMALL ? G_SMALL : G_ROWS_LN, F_HEADS1, a, s);
+  }
+  if (rc) return rc;
+
+  WgradJob jobs[kMaxWgradJobs];
+  int nj = 0;
+  for (int l = (kind == MLP_SMALL_LN ? 1 : 0); l <= top; ++l) {
+    WgradJob& j = jobs[nj++];
+    j.G = wk.g[l]; j.A = (l == 0) ? x : sv.act[l - 1];
+    j.dW = grads[2 * l]; j.db = grads[2 * l + 1];
+    j.R = R; j.ldg = j.lda = j.ldw = (int)D; j.col0 = 0;
+  }
+  if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, s))) return rc;
+
+  SmallWgradArgs sa{};
+  sa.R = R; sa.D = (int)D;
+  if (kind == MLP_SMALL_LN) {          // dW0[f][k] = sum_r g0[r][f] x[r][k] ; db0 = colsum g0
+    sa.G = wk.g[0]; sa.S = x; sa.S_cols = (int)in_dim;
+    sa.out = grads[0]; sa.os = 1; sa.of = in_dim; sa.colsum = grads[1];
+    return launch_small_wgrad(sa, wk.sw, s);
+  }
+  if (kind == MLP_ROWS_SMALL) {        // dW_H[c][f] = sum_r dy[r][c] a_{H-1}[r][f] ; db_H = colsum dy
+    sa.G = sv.act[H - 1]; sa.S = grad_y; sa.S_cols = (int)out_dim;
+    sa.out = grads[2 * H]; sa.os = D; sa.of = 1; sa.colsum_S = grads[2 * H + 1];
+    return launch_small_wgrad(sa, wk.sw, s);
+  }
+  return BSMS_OK;
+}

@@ -1,0 +1,303 @@
+// HBM-bound index kernels of the BSMS path: CSR segmented row sums (edge aggregation, restrict /
+// prolong transitions, gradient scatters), cal_ew, row gathers / scatters.
+//
+// One kernel shape serves all of them:
+//     out[b, r, :] = sum_{q in [rowptr[v], rowptr[v+1])}  w[widx[q]] * X[b, xmap[xidx[q]], :]
+// with v = rows[r] (or r).  Rows are contiguous runs of a sorted CSR, so a destination row is
+// reduced by ONE group of lanes sequentially in the caller's edge order: no atomics, run-to-run
+// reproducible, and bit-identical to a sequential scatter_add_ (utils/basic.py:324-343).
+// Lanes run along the feature axis (16-byte loads, a 128-float row = one 512-byte burst of a
+// half-wave), so every HBM access is a fully used, coalesced row segment.
+#include "common.h"
+
+using namespace bsms;
+
+namespace {
+
+struct RowSumArgs {
+  const int32_t* rowptr;  // [NV+1]
+  const int32_t* rows;    // optional [n_out]: which CSR row feeds output row r
+  const int32_t* xidx;    // optional [E]: slot -> x row (identity if null)
+  const int32_t* xmap;    // optional: second-level map of the x row, negative = skip
+  const float* w;         // optional weights
+  const int32_t* widx;    // optional [E]: slot -> weight index (identity if null)
+  const float* x;
+  float* out;
+  int64_t x_bstride, out_bstride;  // floats per batch item
+  int32_t n_out, B, D;
+};
+
+template <bool WEIGHTED>
+__device__ __forceinline__ float4 accum(float4 acc, float4 v, float w) {
+  if (WEIGHTED) {  // product rounded, then added: same two roundings as x[i]*ew followed by scatter_add_
+    acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, w));
+    acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, w));
+    acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, w));
+    acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, w));
+  } else {
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  return acc;
+}
+
+// LPR lanes cooperate on one output row; each lane owns float4 column groups c4, c4+LPR, ...
+template <int LPR, bool WEIGHTED, bool MAPPED>
+__global__ __launch_bounds__(256) void k_rowsum_v4(RowSumArgs a) {
+  const int64_t worker = (int64_t(blockIdx.x) * 256 + threadIdx.x) / LPR;
+  const int lane = threadIdx.x % LPR;
+  if (worker >= int64_t(a.B) * a.n_out) return;
+  const int b = int(worker / a.n_out), r = int(worker % a.n_out);
+  const int v = a.rows ? a.rows[r] : r;
+  const int q0 = a.rowptr[v], q1 = a.rowptr[v + 1];
+  const float* xb = a.x + b * a.x_bstride;
+  float* ob = a.out + b * a.out_bstride + int64_t(r) * a.D;
+  const int d4 = a.D >> 2;
+  for (int c4 = lane; c4 < d4; c4 += LPR) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int q = q0;
+    for (; q + 4 <= q1; q += 4) {  // 4 independent row loads in flight, summed in order
+      float4 v4[4];
+      float w4[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int xr = a.xidx ? a.xidx[q + u] : q + u;
+        if (MAPPED) xr = a.xmap[xr];
+        live[u] = !MAPPED || xr >= 0;
+        v4[u] = live[u] ? *reinterpret_cast<const float4*>(xb + int64_t(xr) * a.D + c4 * 4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        w4[u] = WEIGHTED ? a.w[a.widx ? a.widx[q + u] : q + u] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (live[u]) acc = accum<WEIGHTED>(acc, v4[u], w4[u]);
+    }
+    for (; q < q1; ++q) {
+      int xr = a.xidx ? a.xidx[q] : q;
+      if (MAPPED) xr = a.xmap[xr];
+      if (MAPPED && xr < 0) continue;
+      float4 v = *reinterpret_cast<const float4*>(xb + int64_t(xr) * a.D + c4 * 4);
+      float w = WEIGHTED ? a.w[a.widx ? a.widx[q] : q] : 1.f;
+      acc = accum<WEIGHTED>(acc, v, w);
+    }
+    *reinterpret_cast<float4*>(ob + c4 * 4) = acc;
+  }
+}
+
+// any D (positions: D = 2 or 3): one thread per output element
+template <bool WEIGHTED, bool MAPPED>
+__global__ __launch_bounds__(256) void k_rowsum_scalar(RowSumArgs a) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t total = int64_t(a.B) * a.n_out * a.D;
+  if (t >= total) return;
+  const int c = int(t % a.D);
+  const int64_t br = t / a.D;
+  const int b = int(br / a.n_out), r = int(br % a.n_out);
+  const int v = a.rows ? a.rows[r] : r;
+  const float* xb = a.x + b * a.x_bstride;
+  float acc = 0.f;
+  for (int q = a.rowptr[v]; q < a.rowptr[v + 1]; ++q) {
+    int xr = a.xidx ? a.xidx[q] : q;
+    if (MAPPED) {
+      xr = a.xmap[xr];
+      if (xr < 0) continue;
+    }
+    float val = xb[int64_t(xr) * a.D + c];
+    if (WEIGHTED) acc = __fadd_rn(acc, __fmul_rn(val, a.w[a.widx ? a.widx[q] : q]));
+    else acc += val;
+  }
+  a.out[b * a.out_bstride + int64_t(r) * a.D + c] = acc;
+}
+
+template <bool WEIGHTED, bool MAPPED>
+int launch_rowsum_wm(const RowSumArgs& a, hipStream_t s) {
+  const int64_t workers = int64_t(a.B) * a.n_out;
+  if (workers == 0 || a.D == 0) return BSMS_OK;
+  if (a.D % 4 != 0) {
+    const int64_t total = workers * a.D;
+    hipLaunchKernelGGL((k_rowsum_scalar<WEIGHTED, MAPPED>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, a);
+  } else {
+    const int d4 = a.D / 4;
+#define BSMS_RS(L)                                                                                      \
+  hipLaunchKernelGGL((k_rowsum_v4<L, WEIGHTED, MAPPED>), dim3((unsigned)ceil_div(workers * L, 256)), \
+                     dim3(256), 0, s, a)
+    if (d4 <= 1) BSMS_RS(1);
+    else if (d4 <= 2) BSMS_RS(2);
+    else if (d4 <= 4) BSMS_RS(4);
+    else if (d4 <= 8) BSMS_RS(8);
+    else if (d4 <= 16) BSMS_RS(16);
+    else if (d4 <= 32) BSMS_RS(32);
+    else BSMS_RS(64);
+#undef BSMS_RS
+  }
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
+
+int launch_rowsum(const RowSumArgs& a, hipStream_t s) {
+  const bool wt = a.w != nullptr, mp = a.xmap != nullptr;
+  if (wt && mp) return launch_rowsum_wm<true, true>(a, s);
+  if (wt) return launch_rowsum_wm<true, false>(a, s);
+  if (mp) return launch_rowsum_wm<false, true>(a, s);
+  return launch_rowsum_wm<false, false>(a, s);
+}
+
+// out[b, oidx[r], :] = in[b, iidx[r], :]   (either index optional)
+template <typename IndexT>
+__global__ __launch_bounds__(256) void k_copy_rows(const float* in, float* out, const IndexT* iidx,
+                                                   const IndexT* oidx, int64_t in_bstride, int64_t out_bstride,
+                                                   int32_t n_rows, int32_t B, int32_t D) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const bool v4 = (D % 4) == 0;
+  const int per_row = v4 ? D / 4 : D;
+  if (t >= int64_t(B) * n_rows * per_row) return;
+  const int c = int(t % per_row);
+  const int64_t br = t / per_row;
+  const int b = int(br / n_rows), r = int(br % n_rows);
+  const int64_t ir = iidx ? int64_t(iidx[r]) : r, orow = oidx ? int64_t(oidx[r]) : r;
+  const float* src = in + b * in_bstride + ir * D;
+  float* dst = out + b * out_bstride + orow * D;
+  if (v4) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(src)[c];
+  else dst[c] = src[c];
+}
+
+__global__ __launch_bounds__(256) void k_cal_ew_nodes(const int32_t* rowptr, const int32_t* src,
+                                                      const int32_t* t_rowptr, const float* w, float* aggr_w,
+                                                      int32_t N) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  float s = 0.f;
+  for (int q = rowptr[j]; q < rowptr[j + 1]; ++q) {
+    const int i = src[q];
+    const float deg = float(t_rowptr[i + 1] - t_rowptr[i]);       // degree(g[0])  utils/basic.py:305-309
+    s = __fadd_rn(s, __fdiv_rn(w[i], deg));                        // ops/basic.py:160-164
+  }
+  aggr_w[j] = __fadd_rn(s, 1e-12f);
+}
+
+__global__ __launch_bounds__(256) void k_cal_ew_edges(const int32_t* src, const int32_t* dst, const int32_t* perm,
+                                                      const int32_t* t_rowptr, const float* w, const float* aggr_w,
+                                                      float* ec, int32_t E) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= E) return;
+  const int i = src[q];
+  const float deg = float(t_rowptr[i + 1] - t_rowptr[i]);
+  ec[perm[q]] = __fdiv_rn(__fdiv_rn(w[i], deg), aggr_w[dst[q]]);   // ops/basic.py:165
+}
+
+}  // namespace
+
+// Exposed to the other translation units of the library (gmp.hip): plan-order segment sums.
+namespace bsms {
+int rowsum_plan_order(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s) {
+  RowSumArgs a{};
+  a.rowptr = p->rowptr;
+  a.x = x; a.out = out;
+  a.x_bstride = p->E * D; a.out_bstride = p->N * D;
+  a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
+  return launch_rowsum(a, s);
+}
+// out[b, i, :] = sum over edges whose SOURCE is i of x[b, slot(e), :]   (x in plan order)
+int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s) {
+  RowSumArgs a{};
+  a.rowptr = p->t_rowptr; a.xidx = p->t_pos;
+  a.x = x; a.out = out;
+  a.x_bstride = p->E * D; a.out_bstride = p->N * D;
+  a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
+  return launch_rowsum(a, s);
+}
+}  // namespace bsms
+
+extern "C" int bsms_segment_sum_fwd(const bsms_plan_t* p, const float* src, int64_t B, int64_t D, int plan_order,
+                                    float* out, bsms_stream_t stream) {
+  BSMS_REQUIRE(p && out && (src || p->E == 0), BSMS_E_INVALID_ARG, "segment_sum_fwd: null argument");
+  BSMS_REQUIRE(B >= 0 && D >= 1, BSMS_E_SHAPE, "segment_sum_fwd: bad B=%lld D=%lld", (long long)B, (long long)D);
+  RowSumArgs a{};
+  a.rowptr = p->rowptr;
+  a.xidx = plan_order ? nullptr : p->perm;
+  a.x = src; a.out = out;
+  a.x_bstride = p->E * D; a.out_bstride = p->N * D;
+  a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
+  return launch_rowsum(a, as_stream(stream));
+}
+
+extern "C" int bsms_segment_sum_bwd(const bsms_plan_t* p, const float* grad_out, int64_t B, int64_t D,
+                                    float* grad_src, bsms_stream_t stream) {
+  BSMS_REQUIRE(p && grad_out && (grad_src || p->E == 0), BSMS_E_INVALID_ARG, "segment_sum_bwd: null argument");
+  BSMS_REQUIRE(B >= 0 && D >= 1, BSMS_E_SHAPE, "segment_sum_bwd: bad B/D");
+  const int per_row = (D % 4 == 0) ? int(D / 4) : int(D);
+  const int64_t total = B * p->E * per_row;
+  if (total == 0) return BSMS_OK;
+  hipLaunchKernelGGL((k_copy_rows<int32_t>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
+                     grad_out, grad_src, (const int32_t*)p->dst, (const int32_t*)p->perm, p->N * D, p->E * D,
+                     (int32_t)p->E, (int32_t)B, (int32_t)D);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
+
+extern "C" int bsms_cal_ew(const bsms_plan_t* p, const float* w, float* ec, float* aggr_w, bsms_stream_t stream) {
+  BSMS_REQUIRE(p && w && aggr_w && (ec || p->E == 0), BSMS_E_INVALID_ARG, "cal_ew: null argument");
+  hipStream_t s = as_stream(stream);
+  if (p->N > 0) {
+    hipLaunchKernelGGL(k_cal_ew_nodes, dim3((unsigned)ceil_div(p->N, 256)), dim3(256), 0, s, p->rowptr, p->src,
+                       p->t_rowptr, w, aggr_w, (int32_t)p->N);
+    BSMS_LAUNCH_CHECK();
+  }
+  if (p->E > 0) {
+    hipLaunchKernelGGL(k_cal_ew_edges, dim3((unsigned)ceil_div(p->E, 256)), dim3(256), 0, s, p->src, p->dst, p->perm,
+                       p->t_rowptr, w, aggr_w, ec, (int32_t)p->E);
+    BSMS_LAUNCH_CHECK();
+  }
+  return BSMS_OK;
+}
+
+extern "C" int bsms_edge_conv(const bsms_plan_t* p, const float* x, int64_t B, int64_t D, const float* ew,
+                              int aggregating, int pooled, float* out, bsms_stream_t stream) {
+  BSMS_REQUIRE(p && x && ew && out, BSMS_E_INVALID_ARG, "edge_conv: null argument");
+  BSMS_REQUIRE(B >= 0 && D >= 1, BSMS_E_SHAPE, "edge_conv: bad B=%lld D=%lld", (long long)B, (long long)D);
+  BSMS_REQUIRE(!pooled || p->ids, BSMS_E_INVALID_ARG, "edge_conv: pooled=1 but the plan has no pool (bsms_plan_set_pool)");
+  RowSumArgs a{};
+  a.w = ew; a.x = x; a.out = out;
+  a.B = (int32_t)B; a.D = (int32_t)D;
+  if (aggregating) {            // by target: fine x -> all rows or kept rows
+    a.rowptr = p->rowptr; a.xidx = p->src; a.widx = p->perm;
+    a.rows = pooled ? p->ids : nullptr;
+    a.n_out = (int32_t)(pooled ? p->Nk : p->N);
+    a.x_bstride = p->N * D;
+  } else {                      // by source: (un-pooled coarse | fine) x -> all fine rows
+    a.rowptr = p->t_rowptr; a.xidx = p->t_dst; a.widx = p->t_eid;
+    a.xmap = pooled ? p->inv : nullptr;
+    a.n_out = (int32_t)p->N;
+    a.x_bstride = (pooled ? p->Nk : p->N) * D;
+  }
+  a.out_bstride = int64_t(a.n_out) * D;
+  return launch_rowsum(a, as_stream(stream));
+}
+
+extern "C" int bsms_scatter_rows(const float* h, int64_t B, int64_t Nk, int64_t D, const int64_t* idx, int64_t N,
+                                 float* out, bsms_stream_t stream) {
+  BSMS_REQUIRE(out && (h || Nk == 0) && (idx || Nk == 0), BSMS_E_INVALID_ARG, "scatter_rows: null argument");
+  BSMS_REQUIRE(B >= 0 && Nk >= 0 && N >= 0 && D >= 1, BSMS_E_SHAPE, "scatter_rows: bad shape");
+  hipStream_t s = as_stream(stream);
+  if (B * N * D > 0) BSMS_HIP_CHECK(hipMemsetAsync(out, 0, size_t(B) * N * D * sizeof(float), s));
+  const int per_row = (D % 4 == 0) ? int(D / 4) : int(D);
+  const int64_t total = B * Nk * per_row;
+  if (total == 0) return BSMS_OK;
+  hipLaunchKernelGGL((k_copy_rows<int64_t>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, h, out,
+                     (const int64_t*)nullptr, idx, Nk * D, N * D, (int32_t)Nk, (int32_t)B, (int32_t)D);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
+
+extern "C" int bsms_gather_rows(const float* x, int64_t B, int64_t N, int64_t D, const int64_t* idx, int64_t Nk,
+                                float* out, bsms_stream_t stream) {
+  BSMS_REQUIRE((out && x && idx) || Nk == 0, BSMS_E_INVALID_ARG, "gather_rows: null argument");
+  BSMS_REQUIRE(B >= 0 && Nk >= 0 && N >= 0 && D >= 1, BSMS_E_SHAPE, "gather_rows: bad shape");
+  const int per_row = (D % 4 == 0) ? int(D / 4) : int(D);
+  const int64_t total = B * Nk * per_row;
+  if (total == 0) return BSMS_OK;
+  hipLaunchKernelGGL((k_copy_rows<int64_t>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), x,
+                     out, idx, (const int64_t*)nullptr, N * D, Nk * D, (int32_t)Nk, (int32_t)B, (int32_t)D);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}

@@ -1,0 +1,121 @@
+"""Data parallelism for the BSMS path: one process per GPU, full model replica, the batch of
+independent meshes sharded across ranks.  Collectives go through
+torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" for the CPU tests):
+
+  * gradients: ONE flat fp32 buffer (7.7 MB for the airfoil model) whose slices are the parameters'
+    `.grad`; it is cut into a few large buckets that are all-reduced (SUM) asynchronously as soon
+    as backward has produced every gradient in the bucket, so the ring transfer hides behind the rest of
+    backward.  xGMI is point-to-point and a ring all-reduce is bound by one link, hence few, large
+    messages rather than per-parameter ones.
+  * loss: the masked RMSE (trainer/trainer.py:96-97) is non-linear in the batch, so the two global
+    sums (sum se*mask, sum mask) are all-reduced BEFORE backward; local gradients are then exact
+    partial derivatives of the global loss and are summed, not averaged.
+  * the reference replaced nothing here: it wraps nn.DataParallel (trainer/trainer.py:15-18) and then
+    disables it (train.py:16); Normalizer.synchronize is dead code (normalizer.py:92-114).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, params, bucket_bytes=2 << 20, group=None):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        order = list(reversed(self.params))  # roughly the order backward produces them
+        total = sum(p.numel() for p in order)
+        dev, dt = order[0].device, order[0].dtype
+        self.flat = torch.zeros(total, device=dev, dtype=dt)
+        self.buckets, self._bucket_of = [], {}
+        off, start, cur = 0, 0, []
+        for p in order:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            cur.append(p)
+            off += n
+            if (off - start) * self.flat.element_size() >= bucket_bytes:
+                self._close(start, off, cur)
+                start, cur = off, []
+        if cur:
+            self._close(start, off, cur)
+        self._pending, self._handles = [len(b["params"]) for b in self.buckets], []
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _close(self, start, end, plist):
+        idx = len(self.buckets)
+        self.buckets.append({"view": self.flat[start:end], "params": list(plist)})
+        for p in plist:
+            self._bucket_of[p] = idx
+
+    def _on_grad(self, p):
+        b = self._bucket_of[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self._world() > 1:
+            self._handles.append(dist.all_reduce(self.buckets[b]["view"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def zero(self):
+        self.flat.zero_()
+        self._pending = [len(b["params"]) for b in self.buckets]
+
+    def finish(self):
+        """Wait for the in-flight bucket reductions (call after backward)."""
+        if self._world() > 1:
+            for b, left in enumerate(self._pending):  # parameters that got no gradient this step
+                if left > 0:
+                    self._handles.append(dist.all_reduce(self.buckets[b]["view"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    def clip_(self, max_norm):
+        """Global-norm clip on the reduced buffer (identical on every rank; trainer/trainer.py:151)."""
+        total = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        return total
+
+
+def global_masked_rmse(pred, tar, mask, group=None):
+    """sqrt(sum_global(se*mask) / sum_global(mask) / C): value identical on all ranks, gradient flows
+    through the local part only (sum over ranks of these local gradients = gradient of the global loss)."""
+    se = (pred - tar) ** 2
+    s_loc, m_loc = (se * mask).sum(), mask.sum()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        tot = torch.stack([s_loc.detach(), m_loc.detach()])
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+        s = s_loc + (tot[0] - s_loc.detach())
+        m = tot[1]
+    else:
+        s, m = s_loc, m_loc
+    return torch.sqrt(s / m / se.shape[-1])
+
+
+class DataParallel:
+    """Wraps a replica: broadcast of parameters at construction, bucketed gradient all-reduce."""
+
+    def __init__(self, model, bucket_bytes=2 << 20, group=None):
+        self.model, self.group = model, group
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0, group=group)
+        self.grads = GradBuckets(list(model.parameters()), bucket_bytes, group)
+
+    def __call__(self, *a, **k):
+        return self.model(*a, **k)
+
+    def step_loss_backward(self, data, consistent_mesh=True):
+        """One fwd + exact global loss + bwd + gradient reduction.  Returns the (global) loss."""
+        self.grads.zero()
+        pred = self.model(data, consistent_mesh, False)
+        loss = global_masked_rmse(pred, data[1] if consistent_mesh else data[0].y.unsqueeze(0),
+                                  data[2] if consistent_mesh else data[0].mask.unsqueeze(0), self.group)
+        loss.backward()
+        self.grads.finish()
+        return loss
+
+    def sync_normalizers(self):
+        for m in self.model.modules():
+            if hasattr(m, "synchronize") and hasattr(m, "_E_data"):
+                m.synchronize(self.group)

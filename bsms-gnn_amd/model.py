@@ -1,0 +1,139 @@
+"""Drop-in for the reference's model layer (src/models/model.py, src/utils/normalizer.py) and the
+loss of src/trainer/trainer.py:96-97.  Encoder, processor (BSGMP) and decoder run on libbsms_hip.so;
+the fp64 normaliser arithmetic on [B,N,<=4] tensors and the masked integration are a handful of
+elementwise PyTorch-ROCm ops (host plumbing)."""
+import torch
+from torch import nn
+
+from .ops import BSGMP, MLP
+
+
+class Normalizer(nn.Module):
+    """utils/normalizer.py:9-114.  Same state_dict keys/dtypes (fp64) as the reference.
+
+    `synchronize()` is the data-parallel reduction the reference left as dead code
+    (normalizer.py:92-114, its call at :37 is commented out): weighted merge of the per-rank
+    accumulators so every rank normalises identically."""
+
+    def __init__(self, size, max_accumulations=10**6, std_epsilon=1e-8, unit=10**6, dtype=torch.float64,
+                 device="cpu", name="Normalizer"):
+        super().__init__()
+        self.name, self.unit, self.size, self.dtype, self.synced = name, unit, size, dtype, False
+        mk = lambda t: nn.Parameter(t, requires_grad=False)
+        self.std_eps = mk(torch.tensor(std_epsilon, dtype=dtype, device=device))
+        self._max_accumulations = mk(torch.tensor(max_accumulations, dtype=dtype, device=device))
+        self._acc_weight = mk(torch.zeros(1, dtype=dtype, device=device))
+        self._num_accumulations = mk(torch.zeros(1, dtype=dtype, device=device))
+        self._E_data = mk(torch.zeros(size, dtype=dtype, device=device))
+        self._E_data_squared = mk(torch.zeros(size, dtype=dtype, device=device))
+
+    def forward(self, batched_data, accumulate=False):
+        if accumulate and bool(self._num_accumulations < self._max_accumulations):
+            self._accumulate(batched_data)
+        return ((batched_data - self.mean()) / self.std_with_epsilon()).type(torch.float32)
+
+    def _accumulate(self, batched_data):
+        rows = batched_data.reshape(-1, self.size)
+        old = self._acc_weight.data
+        dw = torch.tensor(rows.shape[0] / self.unit, dtype=self.dtype, device=rows.device)
+        m1 = torch.mean(rows, dim=0).type(self.dtype)
+        m2 = torch.mean(rows ** 2, dim=0).type(self.dtype)
+        self._acc_weight.data = old.add(dw)
+        self._E_data.data = self._E_data.data.multiply(old).add(m1.multiply(dw)).divide(self._acc_weight)
+        self._E_data_squared.data = self._E_data_squared.data.multiply(old).add(m2.multiply(dw)).divide(self._acc_weight)
+        self._num_accumulations.data = self._num_accumulations.data.add(1.0)
+
+    def inverse(self, normalized_batch_data):
+        return ((normalized_batch_data * self.std_with_epsilon()) + self.mean()).type(torch.float32)
+
+    def mean(self):
+        return self._E_data
+
+    def std_with_epsilon(self):
+        std = torch.sqrt(self._E_data_squared - self.mean() ** 2)
+        return torch.max(torch.nan_to_num(std), self.std_eps)
+
+    def synchronize(self, group=None):
+        """Merge accumulators across ranks (weights add; means are weight-averaged)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            self.synced = True
+            return
+        w = self._acc_weight.data.clone()
+        buf = torch.cat([w, self._num_accumulations.data, self._E_data.data * w, self._E_data_squared.data * w])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        wsum = buf[0:1]
+        self._acc_weight.data = wsum.clone()
+        self._num_accumulations.data = buf[1:2].clone()
+        safe = torch.where(wsum > 0, wsum, torch.ones_like(wsum))
+        self._E_data.data = buf[2:2 + self.size] / safe
+        self._E_data_squared.data = buf[2 + self.size:2 + 2 * self.size] / safe
+        self.synced = True
+
+
+class BSMS_Simulator(nn.Module):
+    """models/model.py:8-208.  forward(data, consistent_mesh, warmup); cfg needs
+    out_dim, latent_dim, hidden_layer, unet_depth, pos_dim (any attribute object)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.encode = MLP(cfg.out_dim + 1, cfg.latent_dim, cfg.latent_dim, cfg.hidden_layer, True)
+        self.process = BSGMP(cfg.unet_depth, cfg.latent_dim, cfg.hidden_layer, cfg.pos_dim)
+        self.decode = MLP(cfg.latent_dim, cfg.latent_dim, cfg.out_dim, cfg.hidden_layer, False)
+        self.pos_dim = cfg.pos_dim
+        self._inputNormalizer = Normalizer(cfg.out_dim + 1, max_accumulations=5e5, name="in_norm")
+        self._targetNormalizer = Normalizer(cfg.out_dim, max_accumulations=5e5, name="out_norm")
+
+    def _get_nodal_latent_input(self, node_in):  # model.py:29-46
+        return torch.cat([node_in[..., : -1 - self.pos_dim], node_in[..., -1:]], dim=-1)
+
+    def _get_pos_type(self, node_in):            # model.py:48-62
+        return node_in[..., -(1 + self.pos_dim): -1].contiguous(), node_in[..., -1].clone()
+
+    def _deltas(self, node_in, node_tar):        # model.py:64-81
+        return node_tar - node_in[..., : node_tar.shape[-1]]
+
+    def _encode_process_decode(self, node_feature, m_ids, multi_gs, pos):  # model.py:83-106
+        x = self.encode(node_feature)
+        x = self.process(x, m_ids, multi_gs, pos)
+        return self.decode(x)
+
+    def _warmup(self, node_in, node_tar):        # model.py:108-125
+        node_in = self._get_nodal_latent_input(node_in)
+        self._inputNormalizer(node_in, accumulate=True)
+        self._targetNormalizer(self._deltas(node_in, node_tar), accumulate=True)
+        return node_tar.new_zeros(node_tar.shape)
+
+    def _forward(self, m_ids, m_gs, node_in, node_mask):  # model.py:127-164
+        node_pos, _ = self._get_pos_type(node_in)
+        node_in = self._get_nodal_latent_input(node_in)
+        norm_in = self._inputNormalizer(node_in, accumulate=False)
+        norm_pred = self._encode_process_decode(norm_in, m_ids, m_gs, node_pos)
+        pred_delta = self._targetNormalizer.inverse(norm_pred) * node_mask
+        return node_in[..., : pred_delta.shape[-1]] + pred_delta
+
+    def forward(self, data, consistent_mesh, warmup):  # model.py:166-208
+        if consistent_mesh:
+            node_in, node_tar, node_mask, m_gs, m_ids = data
+            m_gs = [g[0] for g in m_gs]
+            m_ids = [i[0] for i in m_ids]
+        else:  # PyG-Batch-like objects: block-diagonal graph, batch axis of 1
+            node_in, node_tar, node_mask = data[0].x.unsqueeze(0), data[0].y.unsqueeze(0), data[0].mask.unsqueeze(0)
+            m_gs = [d.edge_index for d in data]
+            m_ids = [data[i].face for i in range(len(m_gs) - 1)]
+        if warmup:
+            return self._warmup(node_in, node_tar)
+        return self._forward(m_ids, m_gs, node_in, node_mask)
+
+
+def masked_rmse(pred, tar, mask):
+    """trainer/trainer.py:96-97."""
+    se = (pred - tar) ** 2
+    return torch.sqrt((se * mask).sum() / mask.sum() / se.shape[-1])
+
+
+def masked_se_sums(pred, tar, mask):
+    """The two global sums of the loss, for the data-parallel exact-RMSE exchange."""
+    se = (pred - tar) ** 2
+    return (se * mask).sum(), mask.sum()

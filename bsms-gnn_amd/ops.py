@@ -1,0 +1,402 @@
+"""Drop-in modules for the reference's `src/ops` layer, running on libbsms_hip.so (HIP, gfx950).
+
+Same constructor / forward signatures and the same `state_dict` keys as the reference
+(/root/reference/src/ops/basic.py, src/ops/BSMS.py, src/utils/basic.py:287-343), so checkpoints and
+call sites carry over unchanged:
+
+    MLP(input_dim, latent_dim, output_dim, hidden_layers, layer_normalized=True).forward(x)
+    GMP(latent_dim, hidden_layer, pos_dim).forward(x, g, pos)
+    WeightedEdgeConv().forward(x, g, ew, aggragating=True) / .cal_ew(w, g)
+    Unpool().forward(h, pre_node_num, idx)
+    BSGMP(unet_depth, latent_dim, hidden_layer, pos_dim).forward(h, m_ids, m_gs, pos)
+    scatter_sum(src, index, dim, out, dim_size), degree(index, num_nodes, dtype)
+
+PyTorch is used for device memory, streams and autograd glue only; every tensor op of the path is a
+call through the C ABI.  There is no CPU fallback: CPU tensors raise."""
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _abi
+from .graph import LevelPlan, plan_for
+
+__all__ = ["MLP", "GMP", "WeightedEdgeConv", "Unpool", "BSGMP", "scatter_sum", "degree"]
+
+
+# ------------------------------------------------------------------------------------ plumbing
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_f32(t, what):
+    if not t.is_cuda:
+        raise _abi.BsmsError(f"{what}: the BSMS engine runs on the GPU only (got a {t.device} tensor); "
+                             "there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise _abi.BsmsError(f"{what}: float32 expected, got {t.dtype}")
+    return t.contiguous()
+
+
+_WORK = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only scratch per (device, stream); kernels of one stream are ordered, so sharing is safe."""
+    key = (device, _stream())
+    buf = _WORK.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WORK[key] = buf
+    return buf
+
+
+def _param_ptrs(params):
+    return _abi.ptr_array([p.data_ptr() for p in params])
+
+
+# --------------------------------------------------------------------------------- tensor prims
+class _SegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, plan: LevelPlan):  # src [B,E,D] in the caller's edge order
+        B, E, D = src.shape
+        out = torch.empty(B, plan.N, D, device=src.device, dtype=src.dtype)
+        _abi.check(_abi.lib().bsms_segment_sum_fwd(plan.handle, src.data_ptr(), B, D, 0, out.data_ptr(), _stream()),
+                   "bsms_segment_sum_fwd")
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        grad = grad.contiguous()
+        B, N, D = grad.shape
+        gsrc = torch.empty(B, ctx.plan.E, D, device=grad.device, dtype=grad.dtype)
+        _abi.check(_abi.lib().bsms_segment_sum_bwd(ctx.plan.handle, grad.data_ptr(), B, D, gsrc.data_ptr(), _stream()),
+                   "bsms_segment_sum_bwd")
+        return gsrc, None
+
+
+def scatter_sum(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
+                dim_size: Optional[int] = None) -> torch.Tensor:
+    """utils/basic.py:324-343.  `index` is the 1-D target list along `dim`; supported layouts are the
+    ones the path uses: src [E] (dim=-1), [E,D] / [B,E,D] (dim=-2)."""
+    if out is not None:
+        raise NotImplementedError("scatter_sum(out=...) is not used on the BSMS path")
+    src = _dev_f32(src, "scatter_sum")
+    nd = src.dim()
+    d = dim if dim >= 0 else nd + dim
+    if index.dim() != 1 or not ((nd == 1 and d == 0) or (nd in (2, 3) and d == nd - 2)):
+        raise NotImplementedError("scatter_sum: only a 1-D index along the edge axis ([E], [E,D], [B,E,D]) is implemented")
+    if dim_size is None:
+        dim_size = 0 if index.numel() == 0 else int(index.max()) + 1
+    plan = _index_plan(index, dim_size)
+    if nd == 1:
+        return _SegmentSum.apply(src.view(1, -1, 1), plan).view(dim_size)
+    if nd == 2:
+        return _SegmentSum.apply(src.unsqueeze(0), plan).squeeze(0)
+    return _SegmentSum.apply(src, plan)
+
+
+_INDEX_PLANS = {}
+
+
+def _index_plan(index, dim_size):
+    """Plan for a bare target index (both COO rows = index); cached on the tensor's storage."""
+    from .graph import _key
+    key = (_key(index), int(dim_size))
+    hit = _INDEX_PLANS.get(key)
+    if hit is None:
+        if len(_INDEX_PLANS) > 256:
+            _INDEX_PLANS.clear()
+        idx = index.detach().to(torch.int64)
+        hit = (LevelPlan(torch.stack([idx, idx]), dim_size, device=index.device), index.untyped_storage())
+        _INDEX_PLANS[key] = hit
+    return hit[0]
+
+
+def degree(index: torch.Tensor, num_nodes: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """utils/basic.py:287-309 -- note the reference IGNORES num_nodes: length is max(index)+1."""
+    n = int(index.max()) + 1
+    ones = torch.ones(index.numel(), device=index.device, dtype=torch.float32)
+    out = scatter_sum(ones, index, dim=-1, dim_size=n)
+    return out if dtype in (None, torch.float32) else out.to(dtype)
+
+
+# ------------------------------------------------------------------------------------------ MLP
+class _MLPFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, hidden, layer_norm, out_dim, *params):
+        R, in_dim = x.shape
+        D = params[0].shape[0]
+        L = _abi.lib()
+        y = torch.empty(R, out_dim, device=x.device, dtype=x.dtype)
+        saved = torch.empty(L.bsms_mlp_saved_bytes(R, in_dim, D, out_dim, hidden), dtype=torch.uint8, device=x.device)
+        work = _workspace(x.device, L.bsms_mlp_work_bytes(R, in_dim, D, out_dim, hidden))
+        pp, keep = _param_ptrs(params)
+        _abi.check(L.bsms_mlp_fwd(x.data_ptr(), R, in_dim, D, out_dim, hidden, int(layer_norm), pp, y.data_ptr(),
+                                  saved.data_ptr(), work.data_ptr(), _stream()), "bsms_mlp_fwd")
+        ctx.save_for_backward(x, saved, *params)
+        ctx.cfg = (hidden, layer_norm, out_dim)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, saved, *params = ctx.saved_tensors
+        hidden, layer_norm, out_dim = ctx.cfg
+        R, in_dim = x.shape
+        D = params[0].shape[0]
+        L = _abi.lib()
+        gy = gy.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        gx = torch.empty_like(x) if (need_dx or in_dim == D) else None
+        grads = [torch.empty_like(p) for p in params]
+        work = _workspace(x.device, L.bsms_mlp_work_bytes(R, in_dim, D, out_dim, hidden))
+        pp, keep = _param_ptrs(params)
+        gp, keep2 = _param_ptrs(grads)
+        _abi.check(L.bsms_mlp_bwd(x.data_ptr(), gy.data_ptr(), R, in_dim, D, out_dim, hidden, int(layer_norm), pp,
+                                  saved.data_ptr(), work.data_ptr(), gx.data_ptr() if gx is not None else None, gp,
+                                  _stream()), "bsms_mlp_bwd")
+        return (gx if need_dx else None, None, None, None, *grads)
+
+
+class MLP(nn.Module):
+    """ops/basic.py:6-23.  Parameters live in `seq.{0,2,4,...}.{weight,bias}` like the reference."""
+
+    def __init__(self, input_dim, latent_dim, output_dim, hidden_layers, layer_normalized=True):
+        super().__init__()
+        mods = []
+        for l in range(hidden_layers):
+            mods += [nn.Linear(input_dim if l == 0 else latent_dim, latent_dim), nn.ReLU()]
+        mods.append(nn.Linear(latent_dim, output_dim))
+        if layer_normalized:
+            mods.append(nn.LayerNorm(output_dim, elementwise_affine=False))
+        self.seq = nn.Sequential(*mods)  # parameter container only; the math runs in HIP
+        self.hidden_layers, self.layer_normalized = hidden_layers, layer_normalized
+        self.input_dim, self.latent_dim, self.output_dim = input_dim, latent_dim, output_dim
+
+    def flat_params(self):
+        out = []
+        for m in self.seq:
+            if isinstance(m, nn.Linear):
+                out += [m.weight, m.bias]
+        return out
+
+    def forward(self, x):
+        x = _dev_f32(x, "MLP")
+        lead = x.shape[:-1]
+        y = _MLPFunction.apply(x.reshape(-1, x.shape[-1]), self.hidden_layers, self.layer_normalized, self.output_dim,
+                               *self.flat_params())
+        return y.view(*lead, self.output_dim)
+
+
+# ------------------------------------------------------------------------------------------ GMP
+class _GMPFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos, plan: LevelPlan, hidden, *params):
+        B, N, D = x.shape
+        p = pos.shape[-1]
+        pos_bstride = N * p if pos.dim() == 3 else 0
+        L = _abi.lib()
+        out = torch.empty_like(x)
+        saved = torch.empty(L.bsms_gmp_saved_bytes(B, N, plan.E, D, hidden), dtype=torch.uint8, device=x.device)
+        work = _workspace(x.device, L.bsms_gmp_work_bytes(B, N, plan.E, D, hidden))
+        pp, keep = _param_ptrs(params)
+        _abi.check(L.bsms_gmp_fwd(plan.handle, x.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
+                                  out.data_ptr(), saved.data_ptr(), work.data_ptr(), _stream()), "bsms_gmp_fwd")
+        ctx.save_for_backward(x, pos, saved, *params)
+        ctx.plan, ctx.hidden = plan, hidden
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, pos, saved, *params = ctx.saved_tensors
+        plan, hidden = ctx.plan, ctx.hidden
+        B, N, D = x.shape
+        p = pos.shape[-1]
+        pos_bstride = N * p if pos.dim() == 3 else 0
+        L = _abi.lib()
+        gout = gout.contiguous()
+        gx = torch.empty_like(x)
+        grads = [torch.empty_like(q) for q in params]
+        work = _workspace(x.device, L.bsms_gmp_work_bytes(B, N, plan.E, D, hidden))
+        pp, keep = _param_ptrs(params)
+        gp, keep2 = _param_ptrs(grads)
+        _abi.check(L.bsms_gmp_bwd(plan.handle, x.data_ptr(), pos.data_ptr(), gout.data_ptr(), B, D, p, pos_bstride,
+                                  hidden, pp, saved.data_ptr(), work.data_ptr(), gx.data_ptr(), gp, _stream()),
+                   "bsms_gmp_bwd")
+        return (gx, None, None, None, *grads)
+
+
+class GMP(nn.Module):
+    """ops/basic.py:26-98.  forward(x, g, pos): x [B,N,C] or [N,C]; g [2,E] int64; pos [B,N,p] or [N,p]."""
+
+    def __init__(self, latent_dim, hidden_layer, pos_dim):
+        super().__init__()
+        self.mlp_node = MLP(2 * latent_dim, latent_dim, latent_dim, hidden_layer)
+        self.mlp_edge = MLP(2 * latent_dim + pos_dim + 1, latent_dim, latent_dim, hidden_layer)
+        self.pos_dim, self.hidden_layer, self.latent_dim = pos_dim, hidden_layer, latent_dim
+
+    def forward(self, x, g, pos, plan: Optional[LevelPlan] = None):
+        if x.dim() not in (2, 3) or pos.dim() not in (2, 3):
+            raise NotImplementedError("Only implemented for dim 2 and 3")
+        x = _dev_f32(x, "GMP")
+        pos = _dev_f32(pos, "GMP")
+        squeeze = x.dim() == 2
+        if squeeze:
+            if pos.dim() == 3:
+                raise NotImplementedError("GMP: 2-D x with 3-D pos is not a layout of the reference")
+            x = x.unsqueeze(0)
+        if plan is None:
+            plan = plan_for(g, x.shape[-2])
+        y = _GMPFunction.apply(x, pos, plan, self.hidden_layer, *self.mlp_node.flat_params(), *self.mlp_edge.flat_params())
+        return y.squeeze(0) if squeeze else y
+
+
+# ---------------------------------------------------------------------------------- transitions
+class _EdgeConvFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ew, plan: LevelPlan, aggregating, pooled):
+        B, _, D = x.shape
+        rows = plan.Nk if (aggregating and pooled) else plan.N
+        out = torch.empty(B, rows, D, device=x.device, dtype=x.dtype)
+        _abi.check(_abi.lib().bsms_edge_conv(plan.handle, x.data_ptr(), B, D, ew.data_ptr(), int(aggregating), int(pooled),
+                                             out.data_ptr(), _stream()), "bsms_edge_conv")
+        ctx.save_for_backward(ew)
+        ctx.cfg = (plan, aggregating, pooled, x.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (ew,) = ctx.saved_tensors
+        plan, aggregating, pooled, n_in = ctx.cfg
+        gout = gout.contiguous()
+        B, _, D = gout.shape
+        gx = torch.empty(B, n_in, D, device=gout.device, dtype=gout.dtype)
+        _abi.check(_abi.lib().bsms_edge_conv(plan.handle, gout.data_ptr(), B, D, ew.data_ptr(), int(not aggregating),
+                                             int(pooled), gx.data_ptr(), _stream()), "bsms_edge_conv(adjoint)")
+        return gx, None, None, None, None
+
+
+def _edge_conv(x, ew, plan, aggregating, pooled):
+    squeeze = x.dim() == 2
+    y = _EdgeConvFunction.apply(x.unsqueeze(0) if squeeze else x, ew, plan, aggregating, pooled)
+    return y.squeeze(0) if squeeze else y
+
+
+class WeightedEdgeConv(nn.Module):
+    """ops/basic.py:101-167."""
+
+    def __init__(self, *args):
+        super().__init__()
+
+    def forward(self, x, g, ew, aggragating=True, plan: Optional[LevelPlan] = None):
+        if x.dim() not in (2, 3):
+            raise NotImplementedError("Only implemented for dim 2 and 3")
+        x = _dev_f32(x, "WeightedEdgeConv")
+        ew = _dev_f32(ew, "WeightedEdgeConv")
+        if plan is None:
+            plan = plan_for(g, x.shape[-2])
+        return _edge_conv(x, ew, plan, bool(aggragating), False)
+
+    @torch.no_grad()
+    def cal_ew(self, w, g, plan: Optional[LevelPlan] = None):
+        w = _dev_f32(w, "cal_ew")
+        n = w.shape[0]
+        if plan is None:
+            plan = plan_for(g, n)
+        if plan.max_source + 1 != n:  # degree() has length max(g[0])+1 (utils/basic.py:305): w / deg would not broadcast
+            raise RuntimeError(f"The size of tensor a ({n}) must match the size of tensor b ({plan.max_source + 1}) "
+                               "at non-singleton dimension 0")
+        w1 = w.reshape(-1).contiguous()
+        ec = torch.empty(plan.E, device=w.device, dtype=torch.float32)
+        aggr_w = torch.empty(n, device=w.device, dtype=torch.float32)
+        _abi.check(_abi.lib().bsms_cal_ew(plan.handle, w1.data_ptr(), ec.data_ptr(), aggr_w.data_ptr(), _stream()),
+                   "bsms_cal_ew")
+        return ec, aggr_w
+
+
+class _ScatterRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, idx, n):
+        B, nk, D = h.shape
+        out = torch.empty(B, n, D, device=h.device, dtype=h.dtype)
+        _abi.check(_abi.lib().bsms_scatter_rows(h.data_ptr(), B, nk, D, idx.data_ptr(), n, out.data_ptr(), _stream()),
+                   "bsms_scatter_rows")
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        gout = gout.contiguous()
+        B, n, D = gout.shape
+        gh = torch.empty(B, idx.numel(), D, device=gout.device, dtype=gout.dtype)
+        _abi.check(_abi.lib().bsms_gather_rows(gout.data_ptr(), B, n, D, idx.data_ptr(), idx.numel(), gh.data_ptr(),
+                                               _stream()), "bsms_gather_rows")
+        return gh, None, None
+
+
+class Unpool(nn.Module):
+    """ops/basic.py:170-201."""
+
+    def __init__(self, *args):
+        super().__init__()
+
+    def forward(self, h, pre_node_num, idx):
+        h = _dev_f32(h, "Unpool")
+        idx = idx.to(torch.int64).contiguous()
+        if h.dim() == 2:
+            return _ScatterRows.apply(h.unsqueeze(0), idx, int(pre_node_num)).squeeze(0)
+        if h.dim() == 3:
+            return _ScatterRows.apply(h, idx, int(pre_node_num))
+        return None  # the reference falls through for other ranks (ops/basic.py:194-201)
+
+
+# ---------------------------------------------------------------------------------------- BSGMP
+class BSGMP(nn.Module):
+    """ops/BSMS.py:8-104: down pass (GMP, restrict), bottom GMP, up pass (prolong, GMP, skip add).
+
+    Restrict = WeightedEdgeConv + index by m_ids fused (only kept rows are computed); prolong = Unpool +
+    WeightedEdgeConv(aggragating=False) fused (zero rows are never materialised)."""
+
+    def __init__(self, unet_depth, latent_dim, hidden_layer, pos_dim):
+        super().__init__()
+        self.bottom_gmp = GMP(latent_dim, hidden_layer, pos_dim)
+        self.down_gmps = nn.ModuleList()
+        self.up_gmps = nn.ModuleList()
+        self.unpools = nn.ModuleList()
+        self.unet_depth = unet_depth
+        self.edge_conv = WeightedEdgeConv()
+        for _ in range(unet_depth):
+            self.down_gmps.append(GMP(latent_dim, hidden_layer, pos_dim))
+            self.up_gmps.append(GMP(latent_dim, hidden_layer, pos_dim))
+            self.unpools.append(Unpool())
+
+    def forward(self, h, m_ids, m_gs, pos):
+        if h.dim() not in (2, 3) or pos.dim() not in (2, 3):
+            raise NotImplementedError("Only implemented for dim 2 and 3")
+        h = _dev_f32(h, "BSGMP")
+        pos = _dev_f32(pos, "BSGMP")
+        L = self.unet_depth
+        skips, skip_pos, ews, plans = [], [], [], []
+        w = torch.ones(pos.shape[-2], device=pos.device, dtype=torch.float32)  # BSMS.py:64
+        for i in range(L):
+            plan = plan_for(m_gs[i], h.shape[-2], m_ids[i])
+            h = self.down_gmps[i](h, m_gs[i], pos, plan=plan)
+            skips.append(h)
+            skip_pos.append(pos)
+            ew, w_full = self.edge_conv.cal_ew(w, m_gs[i], plan=plan)
+            h = _edge_conv(h, ew, plan, True, True)          # conv + pool  (BSMS.py:74,79-83)
+            with torch.no_grad():
+                pos = _edge_conv(pos, ew, plan, True, True)  # BSMS.py:75,85-88 ; pos carries no gradient
+            w = w_full[m_ids[i]]                             # BSMS.py:89
+            ews.append(ew)
+            plans.append(plan)
+        h = self.bottom_gmp(h, m_gs[L], pos, plan=plan_for(m_gs[L], h.shape[-2]))
+        for i in range(L):
+            d = L - 1 - i
+            h = _edge_conv(h, ews[d], plans[d], False, True)  # unpool + conv(aggragating=False)  (BSMS.py:98-100)
+            h = self.up_gmps[i](h, m_gs[d], skip_pos[d], plan=plans[d])
+            h = h + skips[d]
+        return h

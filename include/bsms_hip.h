@@ -1,0 +1,144 @@
+/* bsms_hip.h -- C ABI of libbsms_hip.so: the MI355X (gfx950) engine for the BSMS-GNN hot path.
+ *
+ * The reference (Eydcao/BSMS-GNN @ 2024_10_08) has no FFI layer: its hot path sits behind the
+ * Python nn.Module API of src/ops + src/models.  This header is the boundary a maintainer would
+ * bind instead (ctypes stub in INTEGRATION.md); each entry names the reference code it replaces
+ * (paths relative to /root/reference/src).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  Every call returns 0 (BSMS_OK) or a
+ *     negative bsms_status; bsms_last_error() gives a thread-local message.  Never throws/exits.
+ *   - All tensor arguments are CALLER-OWNED DEVICE pointers: fp32, row-major, contiguous,
+ *     16-byte aligned.  The library never allocates, frees or synchronises on the data path; the
+ *     one exception is bsms_plan_create/destroy, which own the small integer index buffers of a
+ *     mesh level (lifetime = plan).  Scratch ("work") and saved-for-backward ("saved") buffers are
+ *     caller-provided; their sizes come from the *_bytes() queries.
+ *   - Every launch goes to the hipStream_t passed as `stream` (void* here so C callers need no HIP
+ *     headers).  Re-entrant and thread-safe per stream; no global mutable state but the error string.
+ *   - Edge lists follow the reference: g = int64 [2,E], g[0] = source i, g[1] = target j
+ *     (ops/basic.py:66); aggregation target is j.  "Edge order" below = the caller's order of g.
+ *   - `D` (latent width) must be a multiple of 32 for the MLP/GMP entries (MFMA tile width).
+ *   - An MLP is `hidden` x (Linear,ReLU) + Linear (+LayerNorm, no affine, eps 1e-5)
+ *     (ops/basic.py:6-23).  `params` is a HOST array of 2*(hidden+1) device pointers in state_dict
+ *     order: seq.0.weight, seq.0.bias, seq.2.weight, seq.2.bias, ...  Weights are [out,in] row-major
+ *     exactly as torch.nn.Linear stores them.  `grads` arrays have the same order and shapes and
+ *     are OVERWRITTEN (not accumulated).
+ */
+#ifndef BSMS_HIP_H
+#define BSMS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  BSMS_OK = 0,
+  BSMS_E_INVALID_ARG = -1,
+  BSMS_E_SHAPE = -2,
+  BSMS_E_UNSUPPORTED = -3,
+  BSMS_E_HIP = -4
+} bsms_status;
+
+typedef struct bsms_plan bsms_plan_t; /* one mesh level: dst-sorted CSR + src-sorted transpose */
+typedef void* bsms_stream_t;          /* hipStream_t */
+
+int bsms_abi_version(void);           /* bumps when a signature changes */
+const char* bsms_last_error(void);
+
+/* ---------------------------------------------------------------- graph plan (host side) ----
+ * Replaces the per-call index handling of utils/basic.py:312-343 (broadcast + scatter_add_) and
+ * ops/basic.py:66-72,127-138 (x[:, i], x[:, j] gathers): the COO list is turned ONCE per mesh
+ * into a destination-sorted CSR (stable, so each target sums its edges in the caller's edge
+ * order, like a sequential scatter_add_) plus the source-sorted transpose used by the backward
+ * gathers and the up-pass.  `coo_host` is a HOST pointer to int64 [2,E].  Indices must be
+ * < 2^31.  bsms_plan_set_pool attaches the kept-node ids of the level (m_ids[l],
+ * graph_wrappers/bsms_graph_wrapper.py:97-98; HOST int64 [Nk], ascending) for the fused
+ * restrict / prolong kernels. */
+int bsms_plan_create(const int64_t* coo_host, int64_t E, int64_t N, bsms_plan_t** out);
+int bsms_plan_set_pool(bsms_plan_t* plan, const int64_t* ids_host, int64_t Nk);
+int bsms_plan_destroy(bsms_plan_t* plan);
+int64_t bsms_plan_num_nodes(const bsms_plan_t* plan);
+int64_t bsms_plan_num_edges(const bsms_plan_t* plan);
+int64_t bsms_plan_num_pooled(const bsms_plan_t* plan);  /* Nk, 0 if no pool attached */
+int64_t bsms_plan_min_out_degree(const bsms_plan_t* plan);
+int64_t bsms_plan_max_source(const bsms_plan_t* plan);  /* max(g[0]); degree() length-1, utils/basic.py:305 */
+/* debug/test accessors: copy index arrays to HOST int32 buffers (sizes N+1, E, E, E). */
+int bsms_plan_export(const bsms_plan_t* plan, int32_t* rowptr, int32_t* src_sorted,
+                     int32_t* perm, int32_t* t_rowptr);
+
+/* ---------------------------------------------------------------- A1: edge aggregation ------
+ * scatter_sum(src, index=g[1], dim=-2, dim_size=N)  (utils/basic.py:324-343, call site
+ * ops/basic.py:94): out[b,n,:] = sum over edges e with g[1][e]==n of src[b,e,:], summed in edge
+ * order.  plan_order=0: `src` rows are in the caller's edge order; 1: already dst-sorted
+ * (plan order, what the fused GMP path produces).  The backward is the gather grad[b, g[1][e], :]
+ * (autograd of scatter_add_), written in edge order. */
+int bsms_segment_sum_fwd(const bsms_plan_t* plan, const float* src, int64_t B, int64_t D,
+                         int plan_order, float* out, bsms_stream_t stream);
+int bsms_segment_sum_bwd(const bsms_plan_t* plan, const float* grad_out, int64_t B, int64_t D,
+                         float* grad_src, bsms_stream_t stream);
+
+/* ---------------------------------------------------------------- A2+A6: cal_ew -------------
+ * WeightedEdgeConv.cal_ew (ops/basic.py:142-167) incl. degree() (utils/basic.py:287-309):
+ * ec[e] = (w[i]/deg[i]) / (sum_{e'->j} w[i']/deg[i'] + 1e-12), aggr_w[n] = that sum + 1e-12.
+ * `w` [N], `ec` [E] in edge order, `aggr_w` [N]. */
+int bsms_cal_ew(const bsms_plan_t* plan, const float* w, float* ec, float* aggr_w,
+                bsms_stream_t stream);
+
+/* ---------------------------------------------------------------- A5/A7/A8: transitions -----
+ * WeightedEdgeConv.forward (ops/basic.py:107-140), optionally fused with the pooling gather
+ * h[:, m_ids] (ops/BSMS.py:79-89) or with Unpool (ops/basic.py:176-201):
+ *   aggregating=1, pooled=0: out[b,j,:] = sum_{e->j} ew[e]*x[b,i_e,:]          x,out [B,N,D]
+ *   aggregating=1, pooled=1: only kept rows j = ids[k] ("restrict")       x [B,N,D], out [B,Nk,D]
+ *   aggregating=0, pooled=0: out[b,i,:] = sum_{e: i_e=i} ew[e]*x[b,j_e,:]      x,out [B,N,D]
+ *   aggregating=0, pooled=1: x is the coarse tensor [B,Nk,D], zero-filled unpooling is implied
+ *                            ("prolong"): out[b,i,:] = sum_{e: i_e=i, j_e kept} ew[e]*x[b,inv[j_e],:]
+ * Any D >= 1 (also used for positions, D = pos_dim).  `ew` [E] in edge order.  The backward of a
+ * call w.r.t. x is the same entry with `aggregating` flipped (exact adjoint), same `pooled`. */
+int bsms_edge_conv(const bsms_plan_t* plan, const float* x, int64_t B, int64_t D,
+                   const float* ew, int aggregating, int pooled, float* out, bsms_stream_t stream);
+/* standalone Unpool / pooling gather with a DEVICE int64 index (ops/basic.py:194-199, BSMS.py:79-83) */
+int bsms_scatter_rows(const float* h, int64_t B, int64_t Nk, int64_t D, const int64_t* idx_dev,
+                      int64_t N, float* out /* [B,N,D], zero-filled here */, bsms_stream_t stream);
+int bsms_gather_rows(const float* x, int64_t B, int64_t N, int64_t D, const int64_t* idx_dev,
+                     int64_t Nk, float* out /* [B,Nk,D] */, bsms_stream_t stream);
+
+/* ---------------------------------------------------------------- A3: MLP -------------------
+ * MLP.forward (ops/basic.py:6-23) over R rows: x [R,in_dim] -> y [R,out_dim].  Used for the
+ * encoder (in_dim = out_dim_model+1, LN) and decoder (out_dim = C, no LN) of
+ * models/model.py:20-22.  Supported shapes: (in_dim <= 8 or in_dim == D) and
+ * (out_dim == D with layer_norm, or out_dim <= 8 without).  `saved` keeps the activations the backward
+ * needs.  need_dx=0 skips the input gradient (encoder input is data). */
+size_t bsms_mlp_saved_bytes(int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int hidden);
+size_t bsms_mlp_work_bytes(int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int hidden);
+int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int hidden,
+                 int layer_norm, const float* const* params, float* y, void* saved, void* work,
+                 bsms_stream_t stream);
+int bsms_mlp_bwd(const float* x, const float* grad_y, int64_t R, int64_t in_dim, int64_t D,
+                 int64_t out_dim, int hidden, int layer_norm, const float* const* params,
+                 const void* saved, void* work, float* grad_x /* nullable */,
+                 float* const* grads, bsms_stream_t stream);
+
+/* ---------------------------------------------------------------- A4: GMP block -------------
+ * GMP.forward (ops/basic.py:48-98) incl. both MLPs, the gathers, the fiber [pos_i-pos_j, |.|]
+ * and the aggregation: out = mlp_node([x, scatter_sum(mlp_edge([fiber, x_i, x_j]), j)]) + x.
+ * x,out [B,N,D]; pos [B,N,p] (pos_batch_stride = N*p) or [N,p] (pos_batch_stride = 0, the
+ * `repeat` branch ops/basic.py:87-88); 1 <= p <= 7.  `params`: 2*(hidden+1) pointers of mlp_node
+ * followed by 2*(hidden+1) of mlp_edge (state_dict order of a GMP module).  pos gets no gradient
+ * (SURVEY.md quirk 5). */
+size_t bsms_gmp_saved_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden);
+size_t bsms_gmp_work_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden);
+int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float* pos, int64_t B, int64_t D,
+                 int64_t p, int64_t pos_batch_stride, int hidden, const float* const* params,
+                 float* out, void* saved, void* work, bsms_stream_t stream);
+int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float* pos, const float* grad_out,
+                 int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                 const float* const* params, const void* saved, void* work, float* grad_x,
+                 float* const* grads, bsms_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSMS_HIP_H */

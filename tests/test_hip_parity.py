@@ -1,0 +1,343 @@
+"""GPU parity: the HIP path (through the C ABI of libbsms_hip.so) against the CPU oracle and against
+the golden vectors generated from the reference.
+
+Tolerances: integer / index results bit-exact; segment sums, edge weights and transitions are summed in
+the reference's edge order and must be BIT-IDENTICAL to the CPU result; dense fp32 results within
+1e-5 of the tensor scale (max|a-b| / max|b|, BASELINE.json north_star), gradients 2e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import bsms_oracle as ro
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, BWD_TOL = 1e-5, 2e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import bsms_gnn_amd as eng
+    return eng
+
+
+def dev(t):
+    return t.cuda()
+
+
+def load_sd(module, sd):
+    module.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+    return module.cuda()
+
+
+def random_graph(n, e, seed, hub=None):
+    """Directed multigraph with isolated targets (degree-0 rows) and optionally one very high degree row."""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, e)
+    dst = rng.integers(0, max(1, n - n // 8), e)  # the last n/8 nodes receive nothing
+    if hub is not None:
+        dst[: e // 4] = hub                     # a row with degree >= 64
+    return torch.tensor(np.stack([src, dst]), dtype=torch.int64)
+
+
+# ------------------------------------------------------------------------------------ plan / indices
+def test_plan_matches_stable_sort(eng):
+    g = random_graph(97, 1000, 0, hub=5)
+    plan = eng.LevelPlan(g.cuda(), 97)
+    rp, src, perm, trp = plan.export()
+    order = np.argsort(g[1].numpy(), kind="stable")
+    assert np.array_equal(perm, order.astype(np.int32))              # bit-exact indexing
+    assert np.array_equal(src, g[0].numpy()[order].astype(np.int32))
+    assert np.array_equal(rp, np.concatenate([[0], np.cumsum(np.bincount(g[1].numpy(), minlength=97))]).astype(np.int32))
+    assert np.array_equal(trp, np.concatenate([[0], np.cumsum(np.bincount(g[0].numpy(), minlength=97))]).astype(np.int32))
+    with pytest.raises(eng._abi.BsmsError):
+        eng.LevelPlan(torch.tensor([[0, 5], [1, 2]]).cuda(), 3)      # out-of-range endpoint
+
+
+# ------------------------------------------------------------------------------------ A1 segment sum
+@pytest.mark.parametrize("B,D", [(1, 1), (2, 3), (3, 8), (2, 32), (2, 128), (1, 256), (2, 36)])
+def test_segment_sum_bit_exact(eng, B, D):
+    n, e = 203, 3000
+    g = random_graph(n, e, B * 100 + D, hub=7)
+    torch.manual_seed(D)
+    src = torch.randn(B, e, D)
+    want = ro.scatter_sum(src, g[1], -2, n)
+    x = dev(src).requires_grad_(True)
+    got = eng.scatter_sum(x, dev(g[1]), dim=-2, dim_size=n)
+    assert torch.equal(got.cpu(), want)                              # same summation order -> same bits
+    cot = torch.randn(B, n, D)
+    got.backward(dev(cot))
+    assert torch.equal(x.grad.cpu(), cot[:, g[1]])                   # backward = gather by target
+    # empty rows really are zero, 1-D and 2-D layouts
+    assert float(got[:, n - n // 8:].abs().sum()) == 0.0
+    assert torch.equal(eng.scatter_sum(dev(src[0]), dev(g[1]), dim=-2, dim_size=n).cpu(), want[0])
+    assert torch.equal(eng.scatter_sum(dev(src[0, :, 0].contiguous()), dev(g[1]), dim=-1, dim_size=n).cpu(), want[0, :, 0])
+
+
+def test_segment_sum_golden_and_degree(eng, graphs):
+    z = load_golden("prims")
+    for name in ("del64", "del300"):
+        es, _ = graphs.levels(name)
+        n0 = graphs.np(f"{name}/pos").shape[0]
+        got = eng.scatter_sum(dev(z.t(f"{name}/scatter_src")), dev(es[0][1]), dim=-2, dim_size=n0)
+        assert torch.equal(got.cpu(), z.t(f"{name}/scatter_out"))
+        assert torch.equal(eng.degree(dev(es[0][0]), dtype=torch.float).cpu(), z.t(f"{name}/degree"))
+    assert eng.degree(torch.tensor([0, 1, 0, 2, 0]).cuda(), dtype=torch.long).tolist() == [3, 1, 1]
+
+
+def test_empty_and_ragged(eng):
+    g = torch.zeros(2, 0, dtype=torch.int64)
+    out = eng.scatter_sum(torch.zeros(2, 0, 32).cuda(), g[1].cuda(), dim=-2, dim_size=5)
+    assert out.shape == (2, 5, 32) and float(out.abs().sum()) == 0.0
+    g1 = torch.tensor([[0], [0]])
+    assert torch.equal(eng.scatter_sum(torch.ones(1, 1, 4).cuda(), g1[1].cuda(), dim=-2, dim_size=1).cpu(), torch.ones(1, 1, 4))
+
+
+# ------------------------------------------------------------------------------------ A2,A5-A8
+@pytest.mark.parametrize("name", ["del64", "del300"])
+def test_transitions_golden_bit_exact(eng, graphs, name):
+    z = load_golden("prims")
+    es, ids = graphs.levels(name)
+    n0 = graphs.np(f"{name}/pos").shape[0]
+    conv = eng.WeightedEdgeConv()
+    w = torch.ones(n0, 1).cuda()
+    for l in range(len(ids)):                                        # cal_ew chain exactly as BSGMP runs it
+        ew, aw = conv.cal_ew(w, dev(es[l]))
+        assert torch.equal(ew.cpu(), z.t(f"{name}/ew{l}")), l
+        assert torch.equal(aw.cpu(), z.t(f"{name}/aggr_w{l}")), l
+        w = aw[dev(ids[l])]
+    g0, ew = dev(es[0]), dev(z.t(f"{name}/ew0"))
+    x3, x2 = dev(z.t(f"{name}/x3")), dev(z.t(f"{name}/x2"))
+    assert torch.equal(conv(x3, g0, ew).cpu(), z.t(f"{name}/conv_down3"))
+    assert torch.equal(conv(x3, g0, ew, aggragating=False).cpu(), z.t(f"{name}/conv_up3"))
+    assert torch.equal(conv(x2, g0, ew).cpu(), z.t(f"{name}/conv_down2"))
+    assert torch.equal(conv(x2, g0, ew, aggragating=False).cpu(), z.t(f"{name}/conv_up2"))
+    un = eng.Unpool()(dev(z.t(f"{name}/coarse3")), n0, dev(ids[0]))
+    assert torch.equal(un.cpu(), z.t(f"{name}/unpool3"))
+    # fused restrict / prolong == the unfused sequences
+    from bsms_gnn_amd.ops import _edge_conv
+    plan = eng.plan_for(g0, n0, dev(ids[0]))
+    assert torch.equal(_edge_conv(x3, ew, plan, True, True).cpu(), z.t(f"{name}/restrict3"))
+    assert torch.equal(_edge_conv(dev(z.t(f"{name}/coarse3")), ew, plan, False, True).cpu(), z.t(f"{name}/prolong3"))
+    # positions (D = 2) through the scalar path
+    pos = torch.tensor(graphs.np(f"{name}/pos")[:, :2], dtype=torch.float32)
+    assert torch.equal(conv(dev(pos), g0, ew).cpu(), ro.edge_conv(pos, es[0], z.t(f"{name}/ew0")))
+
+
+def test_transition_gradients_and_adjoint(eng, graphs):
+    es, ids = graphs.levels("del300")
+    n0, nk = 300, ids[0].numel()
+    from bsms_gnn_amd.ops import _edge_conv
+    ew_cpu, _ = ro.cal_ew(torch.ones(n0, 1), es[0])
+    plan = eng.plan_for(dev(es[0]), n0, dev(ids[0]))
+    torch.manual_seed(3)
+    h = torch.randn(2, n0, 32, requires_grad=True)
+    c = torch.randn(2, nk, 32, requires_grad=True)
+    hd, cd = dev(h.detach()).requires_grad_(True), dev(c.detach()).requires_grad_(True)
+    r_gpu = _edge_conv(hd, dev(ew_cpu), plan, True, True)
+    p_gpu = _edge_conv(cd, dev(ew_cpu), plan, False, True)
+    r_cpu = ro.edge_conv(h, es[0], ew_cpu)[:, ids[0]]
+    p_cpu = ro.edge_conv(ro.unpool(c, n0, ids[0]), es[0], ew_cpu, False)
+    assert torch.equal(r_gpu.cpu(), r_cpu.detach()) and torch.equal(p_gpu.cpu(), p_cpu.detach())
+    cot_r, cot_p = torch.randn_like(r_cpu), torch.randn_like(p_cpu)
+    (r_gpu * dev(cot_r)).sum().backward()
+    (p_gpu * dev(cot_p)).sum().backward()
+    (r_cpu * cot_r).sum().backward()
+    (p_cpu * cot_p).sum().backward()
+    assert rel_err(hd.grad.cpu(), h.grad) < 1e-6 and rel_err(cd.grad.cpu(), c.grad) < 1e-6
+    lhs = float((r_gpu.double() * cd.detach().double()).sum())          # <R h, c> == <h, P c>
+    rhs = float((hd.detach().double() * p_gpu.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+
+
+def test_cal_ew_degree_quirk(eng):
+    """degree() has length max(g[0])+1: a trailing node without out-edges breaks w/deg."""
+    g = torch.tensor([[0, 1], [1, 2]])  # node 2 never sends
+    with pytest.raises(RuntimeError):
+        eng.WeightedEdgeConv().cal_ew(torch.ones(3, 1).cuda(), g.cuda())
+    with pytest.raises(RuntimeError):
+        ro.cal_ew(torch.ones(3, 1), g)
+
+
+def test_rank_and_device_errors(eng):
+    g = torch.tensor([[0, 1], [1, 0]]).cuda()
+    with pytest.raises(NotImplementedError):
+        eng.GMP(32, 1, 2).cuda()(torch.zeros(1, 1, 2, 32).cuda(), g, torch.zeros(2, 2).cuda())
+    with pytest.raises(NotImplementedError):
+        eng.WeightedEdgeConv()(torch.zeros(1, 1, 2, 8).cuda(), g, torch.ones(2).cuda())
+    with pytest.raises(eng._abi.BsmsError):                             # no CPU fallback
+        eng.GMP(32, 1, 2)(torch.zeros(2, 32), g.cpu(), torch.zeros(2, 2))
+    with pytest.raises(eng._abi.BsmsError):                             # unsupported latent width
+        eng.GMP(48, 1, 2).cuda()(torch.zeros(2, 48).cuda(), g, torch.zeros(2, 2).cuda())
+
+
+# ------------------------------------------------------------------------------------ A3 MLP
+@pytest.mark.parametrize("in_dim,D,out_dim,H,ln,rows", [
+    (3, 32, 32, 3, True, 300),      # encoder shape (C+1 -> D, LayerNorm)
+    (4, 128, 128, 3, True, 1000),
+    (128, 128, 3, 3, False, 1000),  # decoder shape (D -> C, no LayerNorm)
+    (32, 32, 2, 2, False, 77),
+    (64, 64, 64, 1, True, 129),     # generic D -> D
+    (128, 128, 128, 3, True, 513),
+    (256, 256, 256, 2, True, 200),
+])
+def test_mlp_against_oracle(eng, in_dim, D, out_dim, H, ln, rows):
+    torch.manual_seed(in_dim + D + rows)
+    ref = ro.MLP(in_dim, D, out_dim, H, ln)
+    mine = load_sd(eng.MLP(in_dim, D, out_dim, H, ln), ref.state_dict())
+    x = torch.randn(2, rows, in_dim, requires_grad=True)
+    cot = torch.randn(2, rows, out_dim)
+    y = ref(x)
+    (y * cot).sum().backward()
+    xd = dev(x.detach()).requires_grad_(in_dim == D)
+    yd = mine(xd)
+    (yd * dev(cot)).sum().backward()
+    assert rel_err(yd.cpu(), y) < FWD_TOL
+    if in_dim == D:
+        assert rel_err(xd.grad.cpu(), x.grad) < BWD_TOL
+    for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert rel_err(pm.grad.cpu(), pr.grad) < BWD_TOL, k
+
+
+# ------------------------------------------------------------------------------------ A4 GMP
+@pytest.mark.parametrize("tag,D,p", [("d32p2", 32, 2), ("d128p2", 128, 2), ("d32p3", 32, 3)])
+def test_gmp_golden(eng, graphs, tag, D, p):
+    z = load_golden(f"gmp_{tag}")
+    es, _ = graphs.levels(str(z.np("graph")))
+    g = dev(es[0])
+    gmp = load_sd(eng.GMP(D, 3, p), z.state_dict())
+    for xk, pk, yk, dk, gk in (("x3", "pos3", "y33", "dx33", "g33/"), ("x3", "pos2", "y32", "dx32", None),
+                               ("x2", "pos2", "y22", "dx22", "g22/")):
+        gmp.zero_grad()
+        x = dev(z.t(xk)).requires_grad_(True)
+        cot = dev(z.t("cot3")) if xk == "x3" else dev(z.t("cot3")[0])
+        y = gmp(x, g, dev(z.t(pk)))
+        (y * cot).sum().backward()
+        assert rel_err(y.cpu(), z.t(yk)) < FWD_TOL, (xk, pk)
+        assert rel_err(x.grad.cpu(), z.t(dk)) < BWD_TOL, (xk, pk)
+        if gk:
+            for k, prm in gmp.named_parameters():
+                assert rel_err(prm.grad.cpu(), z.t(gk + k)) < BWD_TOL, (k, xk, pk)
+
+
+def test_gmp_degenerate_rows(eng):
+    """Targets with no incoming edge (aggr = 0) and one with degree >= 64, ragged tile tails."""
+    n, e, D = 150, 777, 64
+    g = random_graph(n, e, 9, hub=3)
+    torch.manual_seed(2)
+    ref = ro.GMP(D, 2, 2)
+    mine = load_sd(eng.GMP(D, 2, 2), ref.state_dict())
+    x, pos = torch.randn(3, n, D, requires_grad=True), torch.rand(3, n, 2)
+    y = ref(x, g, pos)
+    y.square().sum().backward()
+    xd = dev(x.detach()).requires_grad_(True)
+    yd = mine(xd, dev(g), dev(pos))
+    yd.square().sum().backward()
+    assert rel_err(yd.cpu(), y) < FWD_TOL and rel_err(xd.grad.cpu(), x.grad) < BWD_TOL
+    for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert rel_err(pm.grad.cpu(), pr.grad) < BWD_TOL, k
+
+
+# ------------------------------------------------------------------------------------ A8,A9 BSGMP
+@pytest.mark.parametrize("tag,D,p", [("line11", 32, 3), ("del300", 32, 2), ("del64_d128", 128, 2)])
+def test_bsgmp_golden(eng, graphs, tag, D, p):
+    z = load_golden(f"bsgmp_{tag}")
+    L = int(z.np("depth"))
+    es, ids = graphs.levels(str(z.np("graph")))
+    net = load_sd(eng.BSGMP(L, D, 3, p), z.state_dict())
+    assert set(net.state_dict()) == set(z.state_dict())                # checkpoint layout identical
+    h = dev(z.t("h")).requires_grad_(True)
+    y = net(h, [dev(i) for i in ids[:L]], [dev(e) for e in es[: L + 1]], dev(z.t("pos")))
+    (y * dev(z.t("cot"))).sum().backward()
+    assert rel_err(y.cpu(), z.t("y")) < FWD_TOL
+    assert rel_err(h.grad.cpu(), z.t("dh")) < BWD_TOL
+    for k, prm in net.named_parameters():
+        assert rel_err(prm.grad.cpu(), z.t("g/" + k)) < BWD_TOL, k
+
+
+# ------------------------------------------------------------------------------------ A10-A12, A16
+def test_simulator_step_and_rollout_golden(eng, graphs):
+    z = load_golden("sim")
+    es, ids = graphs.levels("del300")
+    B = z.np("node_in").shape[0]
+    sim = eng.BSMS_Simulator(ro.make_cfg(2, 32, 3, 3, 2))
+    sd = z.state_dict()
+    assert set(sd) == set(sim.state_dict())
+    m_gs = [dev(e.unsqueeze(0).repeat(B, 1, 1)) for e in es]
+    m_ids = [dev(i.unsqueeze(0).repeat(B, 1)) for i in ids]
+    fresh = eng.BSMS_Simulator(ro.make_cfg(2, 32, 3, 3, 2)).cuda()
+    for k in range(3):                                                # warm-up accumulates fp64 statistics
+        out = fresh((dev(z.t(f"warm_in{k}")), dev(z.t(f"warm_tar{k}")), None, m_gs, m_ids), True, True)
+        assert float(out.abs().sum()) == 0.0
+    for k, v in fresh.state_dict().items():
+        if "Normalizer" in k:
+            assert v.dtype == torch.float64
+            torch.testing.assert_close(v.cpu(), sd[k], rtol=1e-12, atol=0)
+    sim.load_state_dict(sd)
+    sim = sim.cuda()
+    node_in, tar, mask = dev(z.t("node_in")), dev(z.t("tar")), dev(z.t("mask"))
+    pred = sim((node_in, tar, mask, m_gs, m_ids), True, False)
+    loss = eng.masked_rmse(pred, tar, mask)
+    loss.backward()
+    assert rel_err(pred.cpu(), z.t("pred")) < FWD_TOL
+    assert abs(float(loss) - float(z.t("loss"))) < 1e-5 * abs(float(z.t("loss")))
+    for k, prm in sim.named_parameters():
+        if prm.requires_grad:
+            assert rel_err(prm.grad.cpu(), z.t("g/" + k)) < BWD_TOL, k
+    dead = z.t("mask")[..., 0] == 0
+    assert torch.equal(pred.detach().cpu()[dead], z.t("node_in")[..., :2][dead])   # masked nodes untouched (quirk 8)
+    # 5-step autoregressive rollout (utils/rollout_utils.py:14-64)
+    sim.zero_grad()
+    with torch.no_grad():
+        ic, rmask = dev(z.t("rollout_ic")), dev(z.t("rollout_mask"))
+        g1, i1 = [dev(e.unsqueeze(0)) for e in es], [dev(i.unsqueeze(0)) for i in ids]
+        cur, tail, frames = ic.clone(), ic[..., 2:].clone(), []
+        for _ in range(5):
+            pr = sim((cur, torch.zeros_like(cur), rmask, g1, i1), True, False)
+            frames.append(pr[0])
+            cur = torch.where(rmask == 0, ic, torch.cat([pr, tail], -1))
+    assert rel_err(torch.stack(frames).cpu(), z.t("rollout")) < 5e-5
+
+
+# ------------------------------------------------------------------------------------ A15
+def test_block_diagonal_batch(eng, graphs):
+    z = load_golden("blockdiag")
+    net = load_sd(eng.BSGMP(2, 32, 3, 2), z.state_dict())
+    m_gs = [dev(z.t(f"cat/e{l}")) for l in range(3)]
+    m_ids = [dev(z.t(f"cat/ids{l}")) for l in range(2)]
+    h = torch.cat([z.t("del64/h"), z.t("del300/h")])[None]
+    pos = torch.cat([torch.tensor(graphs.np(f"{nm}/pos")[:, :2], dtype=torch.float32) for nm in ("del64", "del300")])[None]
+    with torch.no_grad():
+        y = net(dev(h), m_ids, m_gs, dev(pos)).cpu()
+    assert rel_err(y, z.t("y_cat")) < FWD_TOL
+    assert rel_err(y[0, :64], z.t("del64/y")) < FWD_TOL and rel_err(y[0, 64:], z.t("del300/y")) < FWD_TOL
+
+
+# ------------------------------------------------------------------------------------ full size
+def test_full_size_properties(eng):
+    """BASELINE.json config sizes (airfoil-like, B=8, D=128): size-independent properties."""
+    from bench import build_workload
+    wl = build_workload("airfoil", batch=8, device="cuda")
+    g0, ids0, n0 = wl["m_gs"][0][0], wl["m_ids"][0][0], wl["levels"][0][0]
+    plan = eng.plan_for(g0, n0, ids0)
+    from bsms_gnn_amd.ops import _edge_conv
+    torch.manual_seed(0)
+    a, b = torch.randn(8, g0.shape[1], 128, device="cuda"), torch.randn(8, g0.shape[1], 128, device="cuda")
+    s = lambda t: eng.scatter_sum(t, g0[1], dim=-2, dim_size=n0)
+    assert rel_err(s(a + b), s(a) + s(b)) < 1e-6                       # linearity
+    assert abs(float(s(a).double().sum()) - float(a.double().sum())) < 1e-6 * float(a.abs().double().sum())  # mass
+    ew, _ = eng.WeightedEdgeConv().cal_ew(torch.ones(n0, 1, device="cuda"), g0)
+    ones = eng.scatter_sum(ew, g0[1], dim=-1, dim_size=n0)
+    assert float((ones - 1).abs().max()) < 1e-5                         # weights into a node sum to 1
+    h, c = torch.randn(8, n0, 128, device="cuda"), torch.randn(8, ids0.numel(), 128, device="cuda")
+    lhs = float((_edge_conv(h, ew, plan, True, True).double() * c.double()).sum())
+    rhs = float((h.double() * _edge_conv(c, ew, plan, False, True).double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * abs(lhs)                             # restrict / prolong adjoint
+    # batch independence: dense batch == per-sample results
+    net = eng.BSGMP(2, 128, 3, 2).cuda()
+    with torch.no_grad():
+        x = torch.randn(2, n0, 128, device="cuda")
+        pos = wl["node_in"][:2, :, 3:5].contiguous()
+        both = net(x, [i[0] for i in wl["m_ids"][:2]], [g[0] for g in wl["m_gs"][:3]], pos)
+        one = net(x[1:], [i[0] for i in wl["m_ids"][:2]], [g[0] for g in wl["m_gs"][:3]], pos[1:])
+    assert torch.equal(both[1:], one)
