@@ -10,6 +10,10 @@
 // half-wave), so every HBM access is a fully used, coalesced row segment.
 #include "common.h"
 
+// hipcc defaults to -ffp-contract=fast, which would fuse the rounded product x*ew with the running sum
+// into one FMA; the reference rounds the product first (x[:, i] *= ew, then scatter_add_), so keep them apart.
+#pragma clang fp contract(off)
+
 using namespace bsms;
 
 namespace {
@@ -30,10 +34,8 @@ struct RowSumArgs {
 template <bool WEIGHTED>
 __device__ __forceinline__ float4 accum(float4 acc, float4 v, float w) {
   if (WEIGHTED) {  // product rounded, then added: same two roundings as x[i]*ew followed by scatter_add_
-    acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, w));
-    acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, w));
-    acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, w));
-    acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, w));
+    const float px = v.x * w, py = v.y * w, pz = v.z * w, pw = v.w * w;  // contraction is off in this file
+    acc.x = acc.x + px; acc.y = acc.y + py; acc.z = acc.z + pz; acc.w = acc.w + pw;
   } else {
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void k_rowsum_scalar(RowSumArgs a) {
       if (xr < 0) continue;
     }
     float val = xb[int64_t(xr) * a.D + c];
-    if (WEIGHTED) acc = __fadd_rn(acc, __fmul_rn(val, a.w[a.widx ? a.widx[q] : q]));
+    if (WEIGHTED) { const float prod = val * a.w[a.widx ? a.widx[q] : q]; acc = acc + prod; }
     else acc += val;
   }
   a.out[b * a.out_bstride + int64_t(r) * a.D + c] = acc;

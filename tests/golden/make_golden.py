@@ -71,6 +71,30 @@ def pack_levels(prefix, m_es, m_ids):
     return d
 
 
+class KinkMargin:
+    """Smallest |pre-activation| seen by any ReLU of `model` during the forward passes run inside the
+    `with` block.  The gradient of a ReLU network is discontinuous where a pre-activation crosses 0, and two
+    correct fp32 implementations (different summation order) can land on different sides when |z| is within
+    round-off (~1e-6 here).  Fixtures are therefore drawn (by advancing the seed) until every pre-activation
+    is at least MARGIN away from 0, so gradient parity is well defined."""
+
+    def __init__(self, model):
+        self.model, self.min, self._h = model, float("inf"), []
+
+    def __enter__(self):
+        def hook(_m, inp, _out):
+            self.min = min(self.min, float(inp[0].detach().abs().min()))
+        self._h = [m.register_forward_hook(hook) for m in self.model.modules() if isinstance(m, torch.nn.ReLU)]
+        return self
+
+    def __exit__(self, *a):
+        for h in self._h:
+            h.remove()
+
+
+MARGIN = 1.5e-6
+
+
 def sd_arrays(prefix, module):
     return {f"{prefix}/{k}": t2n(v) for k, v in module.state_dict().items()}
 
@@ -189,116 +213,152 @@ def make_prims(graphs):
     save("prims", **out)
 
 
+def pick_seed(build, first, tries=300):
+    """First seed whose fixture has kink margin > MARGIN, else the best of `tries` (see KinkMargin)."""
+    best_seed, best_margin = None, -1.0
+    for seed in range(first, first + tries):
+        out, margin = build(seed, False)
+        if margin > MARGIN:
+            break
+        if margin > best_margin:
+            best_seed, best_margin = seed, margin
+    else:
+        seed = best_seed
+    out, margin = build(seed, True)
+    out["seed"] = np.int64(seed)
+    out["kink_margin"] = np.float64(margin)
+    return out, seed, margin
+
+
 def make_gmp(graphs):
-    for tag, name, D, p, B in (("d32p2", "del64", 32, 2, 2), ("d128p2", "del300", 128, 2, 2), ("d32p3", "surf200", 32, 3, 2)):
-        out = {}
+    for tag, name, D, p, B in (("d32p2", "del64", 32, 2, 2), ("d128p2", "del300", 128, 2, 1), ("d32p3", "surf200", 32, 3, 2)):
         es, ids = levels_from(graphs, name)
         g = es[0]
         n = graphs[f"{name}/pos"].shape[0]
-        torch.manual_seed(5)
-        gmp = GMP(D, 3, p)
-        out.update(sd_arrays("sd", gmp))
-        pos2 = torch.tensor(graphs[f"{name}/pos"][:, :p], dtype=torch.float32)
-        x3 = torch.randn(B, n, D, requires_grad=True)
-        pos3 = pos2.unsqueeze(0).repeat(B, 1, 1) + 0.01 * torch.randn(B, n, p)
-        cot = torch.randn(B, n, D)
-        # 3-D x, 3-D pos
-        y = gmp(x3, g, pos3)
-        (y * cot).sum().backward()
-        out.update(x3=t2n(x3), pos3=t2n(pos3), cot3=t2n(cot), y33=t2n(y), dx33=t2n(x3.grad))
-        out.update(grad_arrays("g33", gmp))
-        gmp.zero_grad()
-        # 3-D x, 2-D pos (the `repeat` branch, ops/basic.py:87-88)
-        x3b = x3.detach().clone().requires_grad_(True)
-        y = gmp(x3b, g, pos2)
-        (y * cot).sum().backward()
-        out.update(pos2=t2n(pos2), y32=t2n(y), dx32=t2n(x3b.grad))
-        gmp.zero_grad()
-        # 2-D x, 2-D pos
-        x2 = torch.randn(n, D, requires_grad=True)
-        y = gmp(x2, g, pos2)
-        (y * cot[0]).sum().backward()
-        out.update(x2=t2n(x2), y22=t2n(y), dx22=t2n(x2.grad))
-        out.update(grad_arrays("g22", gmp))
-        out["graph"] = np.array(name)
+
+        def build(seed, full):
+            out = {}
+            torch.manual_seed(seed)
+            gmp = GMP(D, 3, p)
+            pos2 = torch.tensor(graphs[f"{name}/pos"][:, :p], dtype=torch.float32)
+            x3 = torch.randn(B, n, D, requires_grad=True)
+            pos3 = pos2.unsqueeze(0).repeat(B, 1, 1) + 0.01 * torch.randn(B, n, p)
+            cot = torch.randn(B, n, D)
+            x3b = x3.detach().clone().requires_grad_(True)
+            x2 = torch.randn(n, D, requires_grad=True)
+            with KinkMargin(gmp) as km:
+                y33 = gmp(x3, g, pos3)   # 3-D x, 3-D pos
+                y32 = gmp(x3b, g, pos2)  # 3-D x, 2-D pos (the `repeat` branch, ops/basic.py:87-88)
+                y22 = gmp(x2, g, pos2)   # 2-D x, 2-D pos
+            if not full:
+                return out, km.min
+            out.update(sd_arrays("sd", gmp))
+            (y33 * cot).sum().backward()
+            out.update(x3=t2n(x3), pos3=t2n(pos3), cot3=t2n(cot), y33=t2n(y33), dx33=t2n(x3.grad))
+            out.update(grad_arrays("g33", gmp))
+            gmp.zero_grad()
+            (y32 * cot).sum().backward()
+            out.update(pos2=t2n(pos2), y32=t2n(y32), dx32=t2n(x3b.grad))
+            gmp.zero_grad()
+            (y22 * cot[0]).sum().backward()
+            out.update(x2=t2n(x2), y22=t2n(y22), dx22=t2n(x2.grad))
+            out.update(grad_arrays("g22", gmp))
+            out["graph"] = np.array(name)
+            return out, km.min
+
+        out, seed, margin = pick_seed(build, 5)
+        print(f"  gmp_{tag}: seed {seed}, kink margin {margin:.2e}")
         save(f"gmp_{tag}", **out)
 
 
 def make_bsgmp(graphs):
-    for tag, name, L, D, p, B in (("line11", "line11", 2, 32, 3, 0), ("del300", "del300", 3, 32, 2, 2), ("del64_d128", "del64", 2, 128, 2, 2)):
-        out = {}
+    for tag, name, L, D, p, B in (("line11", "line11", 2, 32, 3, 0), ("del300", "del300", 3, 32, 2, 1), ("del64_d128", "del64", 2, 128, 2, 2)):
         es, ids = levels_from(graphs, name)
         n = graphs[f"{name}/pos"].shape[0]
-        torch.manual_seed(17)
-        net = BSGMP(L, D, 3, p)
-        out.update(sd_arrays("sd", net))
-        pos = torch.tensor(graphs[f"{name}/pos"][:, :p], dtype=torch.float32)
-        if B == 0:
-            h = torch.randn(n, D, requires_grad=True)
-            pos_in = pos
-        else:
-            h = torch.randn(B, n, D, requires_grad=True)
-            pos_in = pos.unsqueeze(0).repeat(B, 1, 1)
-        cot = torch.randn_like(h)
-        y = net(h, ids[:L], es[: L + 1], pos_in)
-        (y * cot).sum().backward()
-        out.update(h=t2n(h), pos=t2n(pos_in), cot=t2n(cot), y=t2n(y), dh=t2n(h.grad))
-        out.update(grad_arrays("g", net))
-        out["graph"] = np.array(name)
-        out["depth"] = np.int64(L)
+
+        def build(seed, full):
+            out = {}
+            torch.manual_seed(seed)
+            net = BSGMP(L, D, 3, p)
+            pos = torch.tensor(graphs[f"{name}/pos"][:, :p], dtype=torch.float32)
+            if B == 0:
+                h = torch.randn(n, D, requires_grad=True)
+                pos_in = pos
+            else:
+                h = torch.randn(B, n, D, requires_grad=True)
+                pos_in = pos.unsqueeze(0).repeat(B, 1, 1)
+            cot = torch.randn_like(h)
+            with KinkMargin(net) as km:
+                y = net(h, ids[:L], es[: L + 1], pos_in)
+            if not full:
+                return out, km.min
+            out.update(sd_arrays("sd", net))
+            (y * cot).sum().backward()
+            out.update(h=t2n(h), pos=t2n(pos_in), cot=t2n(cot), y=t2n(y), dh=t2n(h.grad))
+            out.update(grad_arrays("g", net))
+            out["graph"] = np.array(name)
+            out["depth"] = np.int64(L)
+            return out, km.min
+
+        out, seed, margin = pick_seed(build, 17)
+        print(f"  bsgmp_{tag}: seed {seed}, kink margin {margin:.2e}")
         save(f"bsgmp_{tag}", **out)
 
 
 def make_sim(graphs):
+    import contextlib
+    import io
     from types import SimpleNamespace
+
+    from utils.rollout_utils import rollout_one_traj
 
     name, L, D, C, p, B = "del300", 3, 32, 2, 2, 2
     es, ids = levels_from(graphs, name)
     n = graphs[f"{name}/pos"].shape[0]
     cfg = SimpleNamespace(out_dim=C, latent_dim=D, hidden_layer=3, unet_depth=L, pos_dim=p)
-    torch.manual_seed(23)
-    import contextlib
-    import io
-
-    with contextlib.redirect_stdout(io.StringIO()):
-        sim = BSMS_Simulator(cfg)
-    sim = sim.to("cpu")
     pos = torch.tensor(graphs[f"{name}/pos"], dtype=torch.float32)
     m_gs = [e.unsqueeze(0).repeat(B, 1, 1) for e in es]
     m_ids = [i.unsqueeze(0).repeat(B, 1) for i in ids]
-    out = {}
-    warm = []
-    for k in range(3):  # three warm-up accumulations (model.py:108-125)
-        state = torch.randn(B, n, C) * (1.0 + k)
-        ntype = (torch.rand(B, n, 1) < 0.1).float()
-        node_in = torch.cat([state, pos.unsqueeze(0).repeat(B, 1, 1), ntype], -1)
-        tar = state + 0.1 * torch.randn(B, n, C)
-        mask = (ntype == 0).float()
-        z = sim((node_in, tar, mask, m_gs, m_ids), True, True)
-        assert float(z.abs().sum()) == 0.0
-        warm.append((node_in, tar))
-        out[f"warm_in{k}"] = t2n(node_in)
-        out[f"warm_tar{k}"] = t2n(tar)
-    out.update(sd_arrays("sd", sim))  # includes fp64 normaliser stats after warm-up
-    node_in, tar = warm[-1]
-    mask = (node_in[..., -1:] == 0).float()
-    pred = sim((node_in, tar, mask, m_gs, m_ids), True, False)
-    se = (pred - tar) ** 2
-    loss = torch.sqrt((se * mask).sum() / mask.sum() / se.shape[-1])  # trainer/trainer.py:96-97
-    loss.backward()
-    out.update(node_in=t2n(node_in), tar=t2n(tar), mask=t2n(mask), pred=t2n(pred), loss=t2n(loss))
-    out.update(grad_arrays("g", sim))
-    # A16: 5-step rollout (utils/rollout_utils.py:14-64), B = 1
-    from utils.rollout_utils import rollout_one_traj
 
-    ic = node_in[:1].clone()
-    results = torch.zeros(5, n, C)
-    tr = SimpleNamespace(model=sim)
-    g1 = [e.unsqueeze(0) for e in es]
-    i1 = [i.unsqueeze(0) for i in ids]
-    rollout_one_traj(tr, ic, results, mask[:1], g1, i1, cfg)
-    out.update(rollout_ic=t2n(ic), rollout_mask=t2n(mask[:1]), rollout=t2n(results))
-    out["graph"] = np.array(name)
+    def build(seed, full):
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim = BSMS_Simulator(cfg).to("cpu")
+        out, warm = {}, []
+        for k in range(3):  # three warm-up accumulations (model.py:108-125)
+            state = torch.randn(B, n, C) * (1.0 + k)
+            ntype = (torch.rand(B, n, 1) < 0.1).float()
+            node_in = torch.cat([state, pos.unsqueeze(0).repeat(B, 1, 1), ntype], -1)
+            tar = state + 0.1 * torch.randn(B, n, C)
+            mask = (ntype == 0).float()
+            z = sim((node_in, tar, mask, m_gs, m_ids), True, True)
+            assert float(z.abs().sum()) == 0.0
+            warm.append((node_in, tar))
+            out[f"warm_in{k}"] = t2n(node_in)
+            out[f"warm_tar{k}"] = t2n(tar)
+        out.update(sd_arrays("sd", sim))  # includes fp64 normaliser stats after warm-up
+        node_in, tar = warm[-1]
+        mask = (node_in[..., -1:] == 0).float()
+        with KinkMargin(sim) as km:
+            pred = sim((node_in, tar, mask, m_gs, m_ids), True, False)
+        if not full:
+            return {}, km.min
+        se = (pred - tar) ** 2
+        loss = torch.sqrt((se * mask).sum() / mask.sum() / se.shape[-1])  # trainer/trainer.py:96-97
+        loss.backward()
+        out.update(node_in=t2n(node_in), tar=t2n(tar), mask=t2n(mask), pred=t2n(pred), loss=t2n(loss))
+        out.update(grad_arrays("g", sim))
+        # A16: 5-step rollout (utils/rollout_utils.py:14-64), B = 1
+        ic = node_in[:1].clone()
+        results = torch.zeros(5, n, C)
+        rollout_one_traj(SimpleNamespace(model=sim), ic, results, mask[:1], [e.unsqueeze(0) for e in es],
+                         [i.unsqueeze(0) for i in ids], cfg)
+        out.update(rollout_ic=t2n(ic), rollout_mask=t2n(mask[:1]), rollout=t2n(results))
+        out["graph"] = np.array(name)
+        return out, km.min
+
+    out, seed, margin = pick_seed(build, 23)
+    print(f"  sim: seed {seed}, kink margin {margin:.2e}")
     save("sim", **out)
 
 
