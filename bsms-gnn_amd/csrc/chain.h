@@ -24,7 +24,7 @@
 namespace bsms {
 
 constexpr int kMaxStages = 8;   // max Linear layers per MLP handled by one chain launch
-constexpr int kTileRows = 128;  // rows of x per workgroup (4 waves x 32)
+constexpr int kTileRows = 64;   // rows of x per workgroup (4 waves x 16)
 
 enum ChainIn { IN_ROWS = 0, IN_ROWS2 = 1, IN_SMALL = 2, IN_EDGE = 3 };
 enum ChainOut { OUT_LN = 0, OUT_PLAIN = 1, OUT_SMALL = 2 };

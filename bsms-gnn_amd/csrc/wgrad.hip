@@ -115,30 +115,53 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradTable tab) {
   if (job.db && bj == 0 && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = csum;
 }
 
-// dW[n][col0+k] = sum over slabs (in order) of the partial blocks; db likewise.
+// dW[n][col0+k] = sum over slabs of the partial blocks; db likewise.  A block owns 64 float4 outputs; its 4
+// "slab lanes" each sum every 4th slab (independent 16-byte loads in flight), then combine in a fixed order
+// through LDS, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradTable tab) {
+  __shared__ float4 red[256];
   const int j = blockIdx.y;
   const WgradJob job = tab.job[j];
-  const int D = tab.D, nblk = tab.nblk;
-  const int total = D * D + (job.db ? D : 0);
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
-    if (o < D * D) {
-      const int n = o / D, k = o % D;
+  const int D = tab.D, nblk = tab.nblk, ns = tab.nsplit[j];
+  const int o4 = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const int nmat = D * D / 4, nall = nmat + (job.db ? D / 4 : 0);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (o4 < nall) {
+    const float* base;
+    int64_t stride;
+    if (o4 < nmat) {
+      const int n = (o4 * 4) / D, k = (o4 * 4) % D;
       const int bi = n / TB, bj = k / TB;
-      float s = 0.f;
-      for (int sp = 0; sp < tab.nsplit[j]; ++sp) {
-        const int tile = tab.first_tile[j] + (sp * nblk + bi) * nblk + bj;
-        s += tab.partials[int64_t(tile) * (TB * TB) + (n % TB) * TB + (k % TB)];
-      }
-      job.dW[int64_t(n) * job.ldw + job.col0 + k] = s;
+      base = tab.partials + int64_t(tab.first_tile[j] + bi * nblk + bj) * (TB * TB) + (n % TB) * TB + (k % TB);
+      stride = int64_t(nblk) * nblk * (TB * TB);
     } else {
-      const int n = o - D * D, bi = n / TB;
-      float s = 0.f;
-      for (int sp = 0; sp < tab.nsplit[j]; ++sp) {
-        const int tile = tab.first_tile[j] + (sp * nblk + bi) * nblk;
-        s += tab.colsums[int64_t(tile) * TB + (n % TB)];
+      const int n = (o4 - nmat) * 4, bi = n / TB;
+      base = tab.colsums + int64_t(tab.first_tile[j] + bi * nblk) * TB + (n % TB);
+      stride = int64_t(nblk) * nblk * TB;
+    }
+    for (int sp = sl; sp < ns; sp += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(base + sp * stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0 && o4 < nall) {
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+      const float4 v = red[l * 64 + threadIdx.x];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (o4 < nmat) {
+      const int n = (o4 * 4) / D, k = (o4 * 4) % D;
+      float* dst = job.dW + int64_t(n) * job.ldw + job.col0 + k;
+      if (((job.ldw | job.col0) & 3) == 0) {
+        *reinterpret_cast<float4*>(dst) = acc;
+      } else {  // sub-block of a wider matrix (edge W0: ld = 2D+p+1, column offset p+1): only 4-byte aligned
+        dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w;
       }
-      job.db[n] = s;
+    } else {
+      *reinterpret_cast<float4*>(job.db + (o4 - nmat) * 4) = acc;
     }
   }
 }
@@ -146,82 +169,97 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradTable tab) {
 constexpr int kMaxTiles = 1024;
 
 // ------------------------------------------------------------------ narrow-side weight gradients
+// out[s][f] = sum_r G[r][f] * S[r][s] with S at most 8 columns wide (the fiber columns of the first edge Linear,
+// the encoder's first and the decoder's last Linear) plus colsum(G).  HBM bound on G: a workgroup streams a slab
+// of rows with 16-byte loads (a row of D floats = one burst of D/4 lanes), 256/(D/4) rows in flight per pass;
+// the narrow row is broadcast.  Per-workgroup partials are combined in fixed order by k_small_reduce.
 constexpr int SW_MAXS = 8;
-constexpr int SW_WGS = 256;
+constexpr int SW_WGS = 1024;
 
-__global__ __launch_bounds__(256) void k_small_wgrad(SmallWgradArgs a, float* part /* [WGS][(S+2)][D] */,
-                                                     int rows_per_wg) {
-  // thread = (feature f, row lane rl); row lanes split the slab, combined through LDS at the end
-  __shared__ float red[256 * (SW_MAXS + 1)];
-  __shared__ float s_sh[8][SW_MAXS];  // per row-lane broadcast of the narrow row
-  const int D = a.D, tid = threadIdx.x;
-  const int nrl = 256 / D > 0 ? 256 / D : 1;
-  const int f = tid % D, rl = tid / D;
-  const bool active = tid < nrl * D;
-  const int S = a.S_cols;
-  float acc[SW_MAXS + 1];
+__device__ __forceinline__ void small_row(const SmallWgradArgs& a, int64_t r, float (&sv)[SW_MAXS]) {
+  if (a.S) {
 #pragma unroll
-  for (int s = 0; s <= SW_MAXS; ++s) acc[s] = 0.f;
-  const int64_t r0 = int64_t(blockIdx.x) * rows_per_wg, r1 = min(a.R, r0 + rows_per_wg);
-  for (int64_t base = r0; base < r1; base += nrl) {
-    const int64_t r = base + rl;
-    const bool rv = active && r < r1;
-    // narrow row -> LDS (one thread per (row lane, s))
-    if (active && f < S && r < r1) {
-      float v;
-      if (a.S) {
-        v = a.S[r * S + f];
-      } else {  // fiber [pos_i - pos_j, |pos_i - pos_j|]  (ops/basic.py:83-85)
-        const int b = int(r / a.E), q = int(r - int64_t(b) * a.E);
-        const int i = a.src[q], jn = a.dst[q];
-        const float* pb = a.pos + b * a.pos_bstride;
-        if (f < a.p) {
-          v = pb[int64_t(i) * a.p + f] - pb[int64_t(jn) * a.p + f];
-        } else {
-          float n2 = 0.f;
-          for (int c = 0; c < a.p; ++c) {
-            const float rel = pb[int64_t(i) * a.p + c] - pb[int64_t(jn) * a.p + c];
-            n2 = fmaf(rel, rel, n2);
-          }
-          v = sqrtf(n2);
-        }
+    for (int s = 0; s < SW_MAXS; ++s) sv[s] = s < a.S_cols ? a.S[r * a.S_cols + s] : 0.f;
+  } else {  // fiber [pos_i - pos_j, |pos_i - pos_j|]  (ops/basic.py:83-85)
+    const int b = int(r / a.E), q = int(r - int64_t(b) * a.E);
+    const int i = a.src[q], jn = a.dst[q];
+    const float* pb = a.pos + b * a.pos_bstride;
+    float n2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < SW_MAXS; ++c) {
+      float rel = 0.f;
+      if (c < a.p) {
+        rel = pb[int64_t(i) * a.p + c] - pb[int64_t(jn) * a.p + c];
+        n2 = fmaf(rel, rel, n2);
       }
-      s_sh[rl][f] = v;
+      sv[c] = rel;
     }
-    __syncthreads();
-    if (rv) {
-      const float g = a.G[r * D + f];
+    const float nrm = sqrtf(n2);
 #pragma unroll
-      for (int s = 0; s < SW_MAXS; ++s)
-        if (s < S) acc[s] = fmaf(g, s_sh[rl][s], acc[s]);
-      acc[SW_MAXS] += g;
-    }
-    __syncthreads();
-  }
-  // combine row lanes
-#pragma unroll
-  for (int s = 0; s <= SW_MAXS; ++s) red[s * 256 + tid] = active ? acc[s] : 0.f;
-  __syncthreads();
-  if (tid < D) {
-    float* out = part + int64_t(blockIdx.x) * (SW_MAXS + 1) * D;
-    for (int s = 0; s <= SW_MAXS; ++s) {
-      float v = 0.f;
-      for (int l = 0; l < nrl; ++l) v += red[s * 256 + l * D + tid];
-      out[s * D + tid] = v;
-    }
+    for (int c = 0; c < SW_MAXS; ++c)
+      if (c == a.p) sv[c] = nrm;
   }
 }
 
+template <int NS>  // NS = number of narrow columns actually accumulated (compile-time for register allocation)
+__global__ __launch_bounds__(256) void k_small_wgrad(SmallWgradArgs a, float* part /* [nwg][SW_MAXS+1][D] */,
+                                                     int rows_per_wg) {
+  __shared__ float4 red[256];
+  const int D = a.D, tid = threadIdx.x, d4 = D >> 2;
+  const int nrl = 256 / d4;                  // rows in flight per pass (D=128: 8)
+  const int c4 = tid % d4, rl = tid / d4;
+  const bool active = rl < nrl;
+  float4 acc[NS + 1];
+#pragma unroll
+  for (int s = 0; s <= NS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t r0 = int64_t(blockIdx.x) * rows_per_wg, r1 = min(a.R, r0 + rows_per_wg);
+  if (active) {
+    for (int64_t r = r0 + rl; r < r1; r += nrl) {
+      const float4 g = *reinterpret_cast<const float4*>(a.G + r * D + c4 * 4);
+      float sv[SW_MAXS];
+      small_row(a, r, sv);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        acc[s].x = fmaf(g.x, sv[s], acc[s].x); acc[s].y = fmaf(g.y, sv[s], acc[s].y);
+        acc[s].z = fmaf(g.z, sv[s], acc[s].z); acc[s].w = fmaf(g.w, sv[s], acc[s].w);
+      }
+      acc[NS].x += g.x; acc[NS].y += g.y; acc[NS].z += g.z; acc[NS].w += g.w;
+    }
+  }
+  float* out = part + int64_t(blockIdx.x) * (SW_MAXS + 1) * D;
+#pragma unroll
+  for (int s = 0; s <= NS; ++s) {  // combine the row lanes in fixed order
+    red[tid] = active ? acc[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tid < d4) {
+      float4 v = red[tid];
+      for (int l = 1; l < nrl; ++l) {
+        const float4 w = red[l * d4 + tid];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      *reinterpret_cast<float4*>(out + (s == NS ? SW_MAXS : s) * D + tid * 4) = v;
+    }
+    __syncthreads();
+  }
+}
+
+// one block per 32 output floats; 8 partial-lanes x 32 outputs, fixed-order combine
 __global__ __launch_bounds__(256) void k_small_reduce(SmallWgradArgs a, const float* part, int nwg) {
+  __shared__ float red[256];
   const int D = a.D, S = a.S_cols;
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= (SW_MAXS + 1) * D) return;
+  const int o = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
   const int s = o / D, f = o % D;
-  if (s < SW_MAXS && s >= S) return;
+  const bool valid = o < (SW_MAXS + 1) * D && (s < S || s == SW_MAXS);
   float v = 0.f;
-  for (int w = 0; w < nwg; ++w) v += part[(int64_t(w) * (SW_MAXS + 1) + s) * D + f];
-  if (s < S) a.out[s * a.os + f * a.of] = v;
-  else if (a.colsum) a.colsum[f] = v;
+  if (valid)
+    for (int w = pl; w < nwg; w += 8) v += part[(int64_t(w) * (SW_MAXS + 1) + s) * D + f];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (pl == 0 && valid) {
+    for (int l = 1; l < 8; ++l) v += red[l * 32 + threadIdx.x];
+    if (s < S) a.out[s * a.os + f * a.of] = v;
+    else if (a.colsum) a.colsum[f] = v;
+  }
 }
 
 // colsum of the narrow matrix itself (decoder output bias): tiny, one workgroup
@@ -285,7 +323,7 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   const size_t lds = size_t(2) * 2 * RC * TB * sizeof(float);
   hipLaunchKernelGGL(k_wgrad, dim3(first), dim3(256), lds, s, tab);
   BSMS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)std::min<int64_t>(ceil_div(D * D + D, 256), 64), njobs), dim3(256), 0, s, tab);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div((D * D + D) / 4, 64), njobs), dim3(256), 0, s, tab);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -295,15 +333,23 @@ size_t small_wgrad_work_bytes(int D) { return size_t(SW_WGS) * (SW_MAXS + 1) * D
 int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s) {
   BSMS_REQUIRE(a.S_cols >= 1 && a.S_cols <= SW_MAXS, BSMS_E_UNSUPPORTED, "small_wgrad: narrow width %d (max %d)", a.S_cols,
                SW_MAXS);
-  BSMS_REQUIRE(a.D >= 32 && a.D <= 256, BSMS_E_UNSUPPORTED, "small_wgrad: D=%d", a.D);
+  BSMS_REQUIRE(a.D >= 32 && a.D <= 256 && a.D % 4 == 0, BSMS_E_UNSUPPORTED, "small_wgrad: D=%d", a.D);
+  BSMS_REQUIRE(a.S != nullptr || a.p + 1 == a.S_cols, BSMS_E_INVALID_ARG, "small_wgrad: fiber mode needs S_cols = p+1");
   float* part = reinterpret_cast<float*>(work);
-  const int nrl = std::max(1, 256 / a.D);
-  int64_t rows_per = std::max<int64_t>(64, ceil_div(a.R, SW_WGS));
+  const int nrl = 256 / (a.D / 4);
+  int64_t rows_per = std::max<int64_t>(4 * nrl, ceil_div(a.R, SW_WGS));
   rows_per = ceil_div(rows_per, nrl) * nrl;
   const int nwg = (int)std::max<int64_t>(1, ceil_div(a.R, rows_per));
-  hipLaunchKernelGGL(k_small_wgrad, dim3(nwg), dim3(256), 0, s, a, part, (int)rows_per);
+#define BSMS_SW(NS)                                                                                   \
+  case NS:                                                                                            \
+    hipLaunchKernelGGL((k_small_wgrad<NS>), dim3(nwg), dim3(256), 0, s, a, part, (int)rows_per); \
+    break
+  switch (a.S_cols) {
+    BSMS_SW(1); BSMS_SW(2); BSMS_SW(3); BSMS_SW(4); BSMS_SW(5); BSMS_SW(6); BSMS_SW(7); BSMS_SW(8);
+  }
+#undef BSMS_SW
   BSMS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)ceil_div((SW_MAXS + 1) * a.D, 256)), dim3(256), 0, s, a, (const float*)part, nwg);
+  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)ceil_div((SW_MAXS + 1) * a.D, 32)), dim3(256), 0, s, a, (const float*)part, nwg);
   BSMS_LAUNCH_CHECK();
   if (a.colsum_S && a.S) {
     hipLaunchKernelGGL(k_colsum_small, dim3(1), dim3(256), 0, s, a.S, a.R, a.S_cols, a.colsum_S);

@@ -18,6 +18,11 @@ import torch.distributed as dist
 
 
 class GradBuckets:
+    """Flat fp32 gradient buffer cut into a few large buckets.  Every parameter owns a slot; the engine's
+    backward kernels write weight gradients directly into the slots (ops._grad_targets), gradients that
+    arrive from plain autograd are copied in by the hook.  A bucket is all-reduced as soon as all of its
+    parameters have their gradient."""
+
     def __init__(self, params, bucket_bytes=2 << 20, group=None):
         self.group = group
         self.params = [p for p in params if p.requires_grad]
@@ -25,11 +30,14 @@ class GradBuckets:
         total = sum(p.numel() for p in order)
         dev, dt = order[0].device, order[0].dtype
         self.flat = torch.zeros(total, device=dev, dtype=dt)
-        self.buckets, self._bucket_of = [], {}
+        self.buckets, self._bucket_of, self._slot = [], {}, {}
         off, start, cur = 0, 0, []
         for p in order:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self._slot[p] = (off, n)
+            p._bsms_grad_slot = (self.flat, off, n)
+            p._bsms_slot_used = False
+            p.grad = None
             cur.append(p)
             off += n
             if (off - start) * self.flat.element_size() >= bucket_bytes:
@@ -48,6 +56,11 @@ class GradBuckets:
             self._bucket_of[p] = idx
 
     def _on_grad(self, p):
+        off, n = self._slot[p]
+        if p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+            view = self.flat[off:off + n].view_as(p)   # gradient produced outside the engine: move it in
+            view.copy_(p.grad)
+            p.grad = view
         b = self._bucket_of[p]
         self._pending[b] -= 1
         if self._pending[b] == 0 and self._world() > 1:
@@ -58,13 +71,16 @@ class GradBuckets:
 
     def zero(self):
         self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+            p._bsms_slot_used = False
         self._pending = [len(b["params"]) for b in self.buckets]
 
     def finish(self):
         """Wait for the in-flight bucket reductions (call after backward)."""
         if self._world() > 1:
-            for b, left in enumerate(self._pending):  # parameters that got no gradient this step
-                if left > 0:
+            for b, left in enumerate(self._pending):  # buckets holding parameters that got no gradient this step
+                if 0 < left:
                     self._handles.append(dist.all_reduce(self.buckets[b]["view"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for h in self._handles:
             h.wait()

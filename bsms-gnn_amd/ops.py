@@ -55,6 +55,23 @@ def _param_ptrs(params):
     return _abi.ptr_array([p.data_ptr() for p in params])
 
 
+def _grad_targets(params):
+    """Where backward writes each weight gradient.  If a data-parallel GradBuckets owns the parameter
+    (dp.py), the kernel writes straight into the parameter's slot of the flat all-reduce buffer: autograd
+    then adopts that view as `.grad` without a copy or an accumulate kernel.  A second use of the same
+    parameter within one step falls back to a fresh tensor (autograd adds it)."""
+    out = []
+    for p in params:
+        slot = getattr(p, "_bsms_grad_slot", None)
+        if slot is not None and p.grad is None and not p._bsms_slot_used:
+            flat, off, n = slot
+            p._bsms_slot_used = True
+            out.append(flat[off:off + n].view_as(p))  # fresh view object: nothing else references it
+        else:
+            out.append(torch.empty_like(p))
+    return out
+
+
 # --------------------------------------------------------------------------------- tensor prims
 class _SegmentSum(torch.autograd.Function):
     @staticmethod
@@ -135,13 +152,15 @@ class _MLPFunction(torch.autograd.Function):
         pp, keep = _param_ptrs(params)
         _abi.check(L.bsms_mlp_fwd(x.data_ptr(), R, in_dim, D, out_dim, hidden, int(layer_norm), pp, y.data_ptr(),
                                   saved.data_ptr(), work.data_ptr(), _stream()), "bsms_mlp_fwd")
-        ctx.save_for_backward(x, saved, *params)
+        ctx.save_for_backward(x, saved)
+        ctx.params = params
         ctx.cfg = (hidden, layer_norm, out_dim)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, saved, *params = ctx.saved_tensors
+        x, saved = ctx.saved_tensors
+        params = ctx.params
         hidden, layer_norm, out_dim = ctx.cfg
         R, in_dim = x.shape
         D = params[0].shape[0]
@@ -149,7 +168,7 @@ class _MLPFunction(torch.autograd.Function):
         gy = gy.contiguous()
         need_dx = ctx.needs_input_grad[0]
         gx = torch.empty_like(x) if (need_dx or in_dim == D) else None
-        grads = [torch.empty_like(p) for p in params]
+        grads = _grad_targets(params)
         work = _workspace(x.device, L.bsms_mlp_work_bytes(R, in_dim, D, out_dim, hidden))
         pp, keep = _param_ptrs(params)
         gp, keep2 = _param_ptrs(grads)
@@ -203,13 +222,15 @@ class _GMPFunction(torch.autograd.Function):
         pp, keep = _param_ptrs(params)
         _abi.check(L.bsms_gmp_fwd(plan.handle, x.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
                                   out.data_ptr(), saved.data_ptr(), work.data_ptr(), _stream()), "bsms_gmp_fwd")
-        ctx.save_for_backward(x, pos, saved, *params)
+        ctx.save_for_backward(x, pos, saved)
+        ctx.params = params
         ctx.plan, ctx.hidden = plan, hidden
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, pos, saved, *params = ctx.saved_tensors
+        x, pos, saved = ctx.saved_tensors
+        params = ctx.params
         plan, hidden = ctx.plan, ctx.hidden
         B, N, D = x.shape
         p = pos.shape[-1]
@@ -217,7 +238,7 @@ class _GMPFunction(torch.autograd.Function):
         L = _abi.lib()
         gout = gout.contiguous()
         gx = torch.empty_like(x)
-        grads = [torch.empty_like(q) for q in params]
+        grads = _grad_targets(params)
         work = _workspace(x.device, L.bsms_gmp_work_bytes(B, N, plan.E, D, hidden))
         pp, keep = _param_ptrs(params)
         gp, keep2 = _param_ptrs(grads)
