@@ -1,23 +1,22 @@
 // MLP "chain" kernels for gfx950: the dense per-edge / per-node MLPs of the BSMS path on f32 MFMA.
 //
 // Orientation.  Every Linear y = x W^T is computed TRANSPOSED, Y^T = W X^T, with
-// v_mfma_f32_32x32x2_f32: the A operand is a weight fragment (rows = output features), the B operand
-// an activation fragment (columns = rows of x, i.e. edges / nodes).  Each wave owns 32 rows of x:
-// lane l <-> row (l & 31), half hh = l >> 5.  The 32x32 result block leaves a lane holding, for ITS
-// row, output features  f = 32 t + (r & 3) + 8 (r >> 2) + 4 hh  (r = accumulator register 0..15).
-// The MFMA sums over k in {0,1} supplied by the two half-waves; we are free to decide WHICH feature
-// each (step s, half hh) stands for, as long as A and B agree.  Choosing
-//          k(s, hh) = 32 kb + (s & 3) + 8 (s >> 2) + 4 hh
-// makes the accumulator layout of one layer exactly the B-operand layout of the next: activations
-// never leave registers between layers -- no LDS round trip, no HBM traffic.  LayerNorm over a row
-// is 64 in-lane values + one cross-half exchange.
+// v_mfma_f32_16x16x4_f32 (exact f32): the A operand is a weight fragment (rows = output features), the B
+// operand an activation fragment (columns = rows of x, i.e. edges / nodes).  Each wave owns 16 rows of x:
+// lane l <-> row (l & 15), lane group g = l >> 4.  The 16x16 result block leaves a lane holding, for ITS row,
+// output features  f = 16 t + 4 g + r  (r = accumulator register 0..3, t = 16-feature block).
+// The MFMA sums over k in {0..3} supplied by the four lane groups; we are free to decide WHICH input feature
+// each (step s, group g) stands for, as long as A and B agree.  Choosing
+//          k(s, g) = 16 kb + 4 g + s
+// makes the accumulator layout of one layer exactly the B-operand layout of the next: activations never
+// leave registers between layers -- no LDS round trip, no HBM traffic.  LayerNorm over a row is 32 in-lane
+// values + two cross-group exchanges.  16-row tiles keep a D=128 kernel near 100-160 VGPRs (3-4 waves/SIMD).
 //
 // Weights are re-laid out once per call ("prepack") into fragment order
-//          Wp[kb][t][s4][lane][c]   (c = s & 3, s4 = s >> 2)      value = W[32 t + (lane & 31)][k(s, lane >> 5)]
-// so that a K-block (32 input features x all outputs; 16 KB at D = 128) is one contiguous chunk: the
-// workgroup streams chunks L2 -> LDS through a 2-deep ring (one barrier per chunk) and every wave
-// reads its A fragments with conflict-free, lane-linear ds_read_b128.  f32 MFMA needs only
-// 16 B/clk/CU of operand bandwidth in this scheme, so the kernels are MFMA-issue bound by design.
+//          Wp[kb][t][lane] = float4{ W[16 t + (lane & 15)][16 kb + 4 (lane >> 4) + 0..3] }
+// (a float4 of the original row-major nn.Linear weight), so a K-chunk (32 input features x all outputs; 16 KB
+// at D = 128) is contiguous: the workgroup streams chunks L2 -> LDS through a 2-deep ring (one barrier per
+// chunk) and every wave reads its A fragments with conflict-free, lane-linear ds_read_b128.
 #pragma once
 #include "common.h"
 

@@ -57,23 +57,27 @@ __global__ __launch_bounds__(256) void k_rowsum_v4(RowSumArgs a) {
   for (int c4 = lane; c4 < d4; c4 += LPR) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int q = q0;
-    for (; q + 4 <= q1; q += 4) {  // 4 independent row loads in flight, summed in order
-      float4 v4[4];
-      float w4[4];
-      bool live[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int xr = a.xidx ? a.xidx[q + u] : q + u;
-        if (MAPPED) xr = a.xmap[xr];
-        live[u] = !MAPPED || xr >= 0;
-        v4[u] = live[u] ? *reinterpret_cast<const float4*>(xb + int64_t(xr) * a.D + c4 * 4)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        w4[u] = WEIGHTED ? a.w[a.widx ? a.widx[q + u] : q + u] : 1.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (live[u]) acc = accum<WEIGHTED>(acc, v4[u], w4[u]);
+    // U independent row loads in flight, summed strictly in edge order (coarse levels have rows of 30-60 edges
+    // and few rows: without enough loads in flight the kernel is pure latency)
+#define BSMS_ROWSUM_BATCH(U)                                                                                  \
+    for (; q + U <= q1; q += U) {                                                                             \
+      float4 v4[U];                                                                                           \
+      float w4[U];                                                                                            \
+      bool live[U];                                                                                           \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                         \
+        int xr = a.xidx ? a.xidx[q + u] : q + u;                                                              \
+        if (MAPPED) xr = a.xmap[xr];                                                                          \
+        live[u] = !MAPPED || xr >= 0;                                                                         \
+        v4[u] = live[u] ? *reinterpret_cast<const float4*>(xb + int64_t(xr) * a.D + c4 * 4)                   \
+                        : make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+        w4[u] = WEIGHTED ? a.w[a.widx ? a.widx[q + u] : q + u] : 1.f;                                         \
+      }                                                                                                       \
+      _Pragma("unroll") for (int u = 0; u < U; ++u)                                                           \
+        if (live[u]) acc = accum<WEIGHTED>(acc, v4[u], w4[u]);                                                \
     }
+    BSMS_ROWSUM_BATCH(8)
+    BSMS_ROWSUM_BATCH(2)
+#undef BSMS_ROWSUM_BATCH
     for (; q < q1; ++q) {
       int xr = a.xidx ? a.xidx[q] : q;
       if (MAPPED) xr = a.xmap[xr];

@@ -243,20 +243,20 @@ __global__ __launch_bounds__(256) void k_small_wgrad(SmallWgradArgs a, float* pa
   }
 }
 
-// one block per 32 output floats; 8 partial-lanes x 32 outputs, fixed-order combine
+// one block per 8 output floats; 32 partial-lanes each sum every 32nd workgroup partial, fixed-order combine
 __global__ __launch_bounds__(256) void k_small_reduce(SmallWgradArgs a, const float* part, int nwg) {
   __shared__ float red[256];
   const int D = a.D, S = a.S_cols;
-  const int o = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+  const int o = blockIdx.x * 8 + (threadIdx.x & 7), pl = threadIdx.x >> 3;
   const int s = o / D, f = o % D;
   const bool valid = o < (SW_MAXS + 1) * D && (s < S || s == SW_MAXS);
   float v = 0.f;
   if (valid)
-    for (int w = pl; w < nwg; w += 8) v += part[(int64_t(w) * (SW_MAXS + 1) + s) * D + f];
+    for (int w = pl; w < nwg; w += 32) v += part[(int64_t(w) * (SW_MAXS + 1) + s) * D + f];
   red[threadIdx.x] = v;
   __syncthreads();
   if (pl == 0 && valid) {
-    for (int l = 1; l < 8; ++l) v += red[l * 32 + threadIdx.x];
+    for (int l = 1; l < 32; ++l) v += red[l * 8 + threadIdx.x];
     if (s < S) a.out[s * a.os + f * a.of] = v;
     else if (a.colsum) a.colsum[f] = v;
   }
@@ -349,7 +349,7 @@ int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s) {
   }
 #undef BSMS_SW
   BSMS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)ceil_div((SW_MAXS + 1) * a.D, 32)), dim3(256), 0, s, a, (const float*)part, nwg);
+  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)ceil_div((SW_MAXS + 1) * a.D, 8)), dim3(256), 0, s, a, (const float*)part, nwg);
   BSMS_LAUNCH_CHECK();
   if (a.colsum_S && a.S) {
     hipLaunchKernelGGL(k_colsum_small, dim3(1), dim3(256), 0, s, a.S, a.R, a.S_cols, a.colsum_S);

@@ -1,0 +1,111 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bsms_hip.h declares; host-side logic
+(hierarchy builder, size queries, argument validation) works without a GPU.  No compute is launched."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import bistride_oracle as bo
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import __graft_entry__
+    __graft_entry__.build()          # hipcc cross-compiles gfx950 without a GPU
+    import bsms_gnn_amd as eng
+    return eng
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bsms_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bsms_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(eng):
+    from bsms_gnn_amd import _abi
+    names = declared_symbols()
+    assert len(names) >= 25
+    lib = C.CDLL(_abi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in bsms_hip.h but not exported"
+    assert set(names) == set(_abi.SIGNATURES), set(names) ^ set(_abi.SIGNATURES)
+    assert _abi.lib().bsms_abi_version() >= 1
+
+
+def test_size_queries_and_validation_without_gpu(eng):
+    L = eng._abi.lib()
+    B, N, E, D, H = 8, 5233, 31354, 128, 3
+    saved, work = L.bsms_gmp_saved_bytes(B, N, E, D, H), L.bsms_gmp_work_bytes(B, N, E, D, H)
+    assert saved > (H + 1) * B * E * D * 4 and work > (H + 1) * B * E * D * 4     # edge activations / gradients dominate
+    assert L.bsms_gmp_saved_bytes(B, N, E, D, 0) == 0 and L.bsms_mlp_saved_bytes(100, 3, D, D, 99) == 0
+    assert L.bsms_mlp_saved_bytes(1000, 4, 128, 128, 3) >= 4 * 1000 * 128 * 4
+    # null / unsupported arguments come back as error codes with a message, never a crash
+    assert L.bsms_gmp_fwd(None, None, None, 1, 128, 2, 0, 3, None, None, None, None, None) == -1
+    assert b"plan is null" in L.bsms_last_error()
+    assert L.bsms_mlp_fwd(None, 10, 5, 48, 48, 3, 1, None, None, None, None, None) == -3      # D = 48
+    assert b"not supported" in L.bsms_last_error()
+    assert L.bsms_plan_destroy(None) == 0 and L.bsms_plan_num_nodes(None) == -1
+
+
+def test_no_cpu_fallback(eng):
+    """The product path must fail loudly instead of degrading to PyTorch when used without a GPU."""
+    g = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(eng._abi.BsmsError):
+        eng.GMP(32, 1, 2)(torch.zeros(2, 32), g, torch.zeros(2, 2))
+    with pytest.raises(eng._abi.BsmsError):
+        eng.scatter_sum(torch.zeros(2, 4), torch.tensor([0, 0]), dim=-2, dim_size=1)
+    with pytest.raises(eng._abi.BsmsError):
+        eng.MLP(3, 32, 32, 2)(torch.zeros(5, 3))
+    if not torch.cuda.is_available():
+        with pytest.raises(eng._abi.BsmsError):
+            eng.LevelPlan(g, 2, device="cpu")
+
+
+def test_state_dict_layout_matches_reference(eng):
+    """108 keys at depth 2, identical names/shapes/dtypes to the golden checkpoint."""
+    from conftest import load_golden
+    from oracle import bsms_oracle as ro
+    z = load_golden("sim")
+    sim = eng.BSMS_Simulator(ro.make_cfg(2, 32, 3, 3, 2))
+    sd, ref = sim.state_dict(), z.state_dict()
+    assert set(sd) == set(ref)
+    for k in sd:
+        assert sd[k].shape == ref[k].shape and sd[k].dtype == ref[k].dtype, k
+    sim.load_state_dict(ref)
+    assert len(eng.BSMS_Simulator(ro.make_cfg(2, 32, 3, 2, 2)).state_dict()) == 108
+    n = sum(p.numel() for p in eng.BSMS_Simulator(ro.make_cfg(3, 128, 3, 5, 2)).parameters() if p.requires_grad)
+    assert n == 1917827                                                     # airfoil model, SURVEY.md section 8b
+
+
+@pytest.mark.parametrize("name,depth", [("line11", 2), ("cyc6bi", 1), ("del64", 3), ("del300", 3), ("surf200", 3)])
+def test_product_hierarchy_builder(eng, graphs, name, depth):
+    """bsms_gnn_amd.hierarchy (SciPy-accelerated host builder) == golden m_ids bit-exact, coarse edges as sets."""
+    es, ids = graphs.levels(name)
+    n = graphs.np(f"{name}/pos").shape[0]
+    _, m_es, m_ids = eng.BistrideMultiLayerGraph(es[0].numpy(), depth, n, graphs.np(f"{name}/pos")).get_multi_layer_graphs()
+    for mine, ref in zip(m_ids, ids):
+        assert mine.dtype == np.int64 and np.array_equal(mine, ref.numpy())
+    for mine, ref in zip(m_es, es):
+        assert np.array_equal(bo.canonical_edges(np.asarray(mine)), bo.canonical_edges(ref.numpy()))
+
+
+@pytest.mark.parametrize("name,kind", [("del64", "tri"), ("surf200", "tri"), ("quad", "quad"), ("tetra", "tetra"), ("line", "line")])
+def test_product_to_flat_edge(eng, graphs, name, kind):
+    assert np.array_equal(eng.to_flat_edge(graphs.np(f"{name}/cells"), kind), graphs.np(f"{name}/e0"))
+    with pytest.raises(ValueError):
+        eng.to_flat_edge(np.zeros((1, 3), dtype=np.int64), "hexa")
+
+
+def test_bench_workload_sizes(eng):
+    """The synthetic airfoil-like workload has exactly the level sizes quoted in SURVEY.md section 8."""
+    from bench import build_mesh
+    _, m_es, m_ids = build_mesh("airfoil")
+    assert [e.shape[1] for e in m_es] == [31354, 25362, 20896, 16076, 10078, 3878]
+    assert [len(i) for i in m_ids] == [2609, 1263, 591, 236, 70]
+    _, m_es, m_ids = build_mesh("cylinder")
+    assert [e.shape[1] for e in m_es] == [11264, 9120, 7574, 5628, 3280] and [len(i) for i in m_ids] == [937, 448, 206, 61]

@@ -1,0 +1,94 @@
+"""CPU, world_size 2 over gloo: the data-parallel wrapper (bsms_gnn_amd.dp) -- bucketed gradient all-reduce,
+exact global masked RMSE, normaliser synchronisation -- reproduces the single-process large-batch result.
+The replica here is the CPU oracle model (the HIP engine needs a GPU); dp.py is model-agnostic."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from conftest import Golden
+    from oracle import bsms_oracle as ro
+    import bsms_gnn_amd.dp as dp                       # imports without touching the GPU
+    from bsms_gnn_amd.model import Normalizer
+
+    graphs = Golden("graphs")
+    es, ids = graphs.levels("del64")
+    n, B = 64, 4                                        # global batch 4 -> 2 per rank
+    cfg = ro.make_cfg(2, 32, 2, 2, 2)
+    torch.manual_seed(100 + rank)                       # different init per rank: broadcast must fix it
+    model = ro.BSMS_Simulator(cfg)
+    gen = torch.Generator().manual_seed(7)
+    pos = torch.tensor(graphs.np("del64/pos"), dtype=torch.float32)
+    state = torch.randn(B, n, 2, generator=gen)
+    ntype = (torch.rand(B, n, 1, generator=gen) < 0.2).float()
+    node_in = torch.cat([state, pos.expand(B, n, 2), ntype], -1)
+    tar = state + 0.1 * torch.randn(B, n, 2, generator=gen)
+    mask = (ntype == 0).float()
+    gs = lambda b: [e.unsqueeze(0).repeat(b, 1, 1) for e in es[:3]]
+    iis = lambda b: [i.unsqueeze(0).repeat(b, 1) for i in ids[:2]]
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    local = (node_in[sl], tar[sl], mask[sl], gs(B // world), iis(B // world))
+
+    engine = dp.DataParallel(model, bucket_bytes=16 << 10)      # several buckets
+    assert len(engine.grads.buckets) > 2
+    model(local, True, True)                                    # per-rank normaliser accumulation ...
+    # ... merged with the product's Normalizer.synchronize arithmetic (run on the oracle's identical fields)
+    for nm in (model._inputNormalizer, model._targetNormalizer):
+        Normalizer.synchronize(nm, None)
+    loss = engine.step_loss_backward(local, True)
+    total = engine.grads.clip_(1e9)
+    res = {"loss": loss.detach(), "flat": engine.grads.flat.clone(), "norm": total,
+           "stats": torch.cat([model._inputNormalizer._E_data, model._targetNormalizer._E_data_squared]),
+           "p0": next(model.parameters()).detach().clone()}
+    # every parameter's .grad is a view of the flat buffer
+    for p in engine.grads.params:
+        off, cnt = engine.grads._slot[p]
+        assert p.grad.data_ptr() == engine.grads.flat.data_ptr() + 4 * off
+    # second step after zero(): same result (hooks re-arm)
+    loss2 = engine.step_loss_backward(local, True)
+    assert torch.allclose(loss2, loss) and torch.allclose(engine.grads.flat, res["flat"], rtol=1e-6, atol=1e-8)
+    if rank == 0:
+        # reference: one process, whole batch, same (rank-0) initial weights
+        torch.manual_seed(100)
+        ref = ro.BSMS_Simulator(cfg)
+        whole = (node_in, tar, mask, gs(B), iis(B))
+        # the merged statistics equal sequential accumulation of the two half batches
+        ref((node_in[:2], tar[:2], mask[:2], gs(2), iis(2)), True, True)
+        ref((node_in[2:], tar[2:], mask[2:], gs(2), iis(2)), True, True)
+        l = ro.masked_rmse(ref(whole, True, False), tar, mask)
+        l.backward()
+        res["ref_loss"] = l.detach()
+        res["ref_flat"] = torch.cat([p.grad.reshape(-1) for p in reversed([q for q in ref.parameters() if q.requires_grad])])
+        res["ref_stats"] = torch.cat([ref._inputNormalizer._E_data, ref._targetNormalizer._E_data_squared])
+        res["ref_p0"] = next(ref.parameters()).detach().clone()
+    torch.save(res, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradients_match_single_process(tmp_path):
+    port = 29500 + os.getpid() % 2000
+    out = str(tmp_path / "res")
+    mp.start_processes(_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["p0"], r1["p0"]) and torch.equal(r0["p0"], r0["ref_p0"])       # broadcast from rank 0
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["loss"], r1["loss"])   # ranks agree bit-for-bit
+    torch.testing.assert_close(r0["stats"], r0["ref_stats"], rtol=1e-12, atol=1e-15)     # fp64 normaliser merge
+    torch.testing.assert_close(r0["stats"], r1["stats"], rtol=0, atol=0)
+    torch.testing.assert_close(r0["loss"], r0["ref_loss"], rtol=1e-6, atol=0)            # exact global RMSE
+    err = (r0["flat"] - r0["ref_flat"]).abs().max() / r0["ref_flat"].abs().max()
+    assert err < 1e-5, err                                                                 # summed grads == big batch
+    assert abs(float(r0["norm"]) - float(r0["ref_flat"].norm())) < 1e-4 * float(r0["ref_flat"].norm())
