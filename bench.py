@@ -77,41 +77,58 @@ def data_tuple(wl):
     return (wl["node_in"], wl["target"], wl["mask"], wl["m_gs"], wl["m_ids"])
 
 
-def cpu_baseline(kind, batch, steps=2):
-    """The oracle (CPU restatement of the reference path) on the host cores, same workload."""
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota (a 256-thread host often
+    hands a container far fewer; 256 torch threads on a quota of a few cores is 30x slower than 8 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(kind, batch, budget_s=25.0):
+    """The oracle (CPU restatement of the reference path) on the host cores, same workload, bounded time."""
     from oracle import bsms_oracle as ro
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = max(1, min(usable_cpus(), 32))       # the reference's small per-level ops stop scaling beyond this
+    torch.set_num_threads(threads)
     wl = build_workload(kind, batch, "cpu")
     torch.manual_seed(0)
     sim = ro.BSMS_Simulator(make_cfg(wl["cfg"]))
     data = data_tuple(wl)
     sim(data, True, True)
-    best = float("inf")
-    for it in range(steps + 1):  # first one is the warm-up
+    times, t_start = [], time.perf_counter()
+    while len(times) < 3 and (len(times) < 1 or time.perf_counter() - t_start < budget_s):
         sim.zero_grad(set_to_none=True)
         t0 = time.perf_counter()
         loss = ro.masked_rmse(sim(data, True, False), wl["target"], wl["mask"])
         loss.backward()
-        dt = time.perf_counter() - t0
-        if it > 0:
-            best = min(best, dt)
-    return {"value": 1.0 / best, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{kind}-like B={batch} fwd+loss+bwd, 1 warm-up + best of {steps} steps, fp32, torch CPU {torch.__version__}",
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:]) if len(times) > 1 else times[0]   # first step doubles as warm-up when there is time
+    return {"value": 1.0 / best, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{kind}-like B={batch} fwd+loss+bwd, {len(times)} step(s) within a {budget_s:.0f} s budget "
+                      f"(best of the non-warm-up ones), fp32, torch CPU {torch.__version__}, "
+                      f"{threads} threads of {os.cpu_count()} logical CPUs",
             "ms_per_step": best * 1e3}
 
 
 def time_kernel(fn, iters=50, warm=5):
-    """Average duration (ms) of `fn`'s launches with HIP events on the launching (current) stream."""
+    """Average duration (ms) of ONE launch of `fn`: every launch is bracketed by its own HIP event pair on the
+    launching (current) stream -- the same quantity rocprofv3's kernel trace reports per dispatch (timing a
+    back-to-back batch with one pair would hide the drain of each kernel behind the start of the next)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in pairs:
+        a.record()
         fn()
-    b.record()
+        b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters
+    return sum(a.elapsed_time(b) for a, b in pairs) / iters
 
 
 def roofline_objects(wl, batch):
@@ -131,9 +148,14 @@ def roofline_objects(wl, batch):
     ms = time_kernel(agg)
     s = 4
     algo = batch * e0 * D * s + batch * n0 * D * s + 4 * (n0 + 1) + 4 * e0
+    traffic = None
+    try:   # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/*_traffic.json)
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "aggregation_traffic.json")))["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roof = {"kernel": "k_rowsum_v4<32,false,false> (L0 edge aggregation, bsms_segment_sum_fwd plan order)",
             "bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": algo, "avg_us": ms * 1e3}
+            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": algo, "avg_us": ms * 1e3}
     # edge-MLP forward through a GMP at L0: flops of the three D x D Linears per edge row
     gmp = eng.GMP(D, 3, wl["cfg"]["pos_dim"]).cuda()
     x = torch.randn(batch, n0, D, device="cuda")
@@ -157,6 +179,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="batch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="only the kernel micro-loops (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -174,6 +197,10 @@ def main():
 
     import bsms_gnn_amd as eng
     wl = build_workload(args.workload, args.batch, "cuda", seed=rank)   # each rank its own samples of the shared mesh
+    if args.roofline_only:
+        roof, mf = roofline_objects(wl, args.batch)
+        print(json.dumps({"roofline": roof, "roofline_mfma": mf}))
+        return
     torch.manual_seed(0)
     sim = eng.BSMS_Simulator(make_cfg(wl["cfg"])).cuda()
     data = data_tuple(wl)
