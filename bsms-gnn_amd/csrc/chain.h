@@ -23,7 +23,8 @@
 namespace bsms {
 
 constexpr int kMaxStages = 8;   // max Linear layers per MLP handled by one chain launch
-constexpr int kTileRows = 64;   // rows of x per workgroup (4 waves x 16)
+constexpr int kTileRows = 64;   // rows of x per workgroup (4 compute waves x 16)
+constexpr int kChainThreads = 320;  // 4 compute waves + 1 loader wave
 
 enum ChainIn { IN_ROWS = 0, IN_ROWS2 = 1, IN_SMALL = 2, IN_EDGE = 3 };
 enum ChainOut { OUT_LN = 0, OUT_PLAIN = 1, OUT_SMALL = 2 };
@@ -60,6 +61,12 @@ struct ChainFwdArgs {
   const float* wout;  // OUT_SMALL: [C][D]
   const float* bout;  // OUT_SMALL: [C]
   int C;
+  int store_mode;     // saved-activation stores: 0 plain, 1 non-temporal (keeps L2 for weights / gathered rows)
+  int out_mode;       // same for the final output y
+  // ---- filled by launch_chain_fwd: weight packs / biases in execution order for the loader wave
+  int nseq;
+  const float4* wseq[kMaxStages + 2];
+  const float* bseq[kMaxStages + 2];
 };
 
 struct ChainBwdArgs {
@@ -80,6 +87,10 @@ struct ChainBwdArgs {
   const float4 *wh0, *wh1;
   float *dx, *dx2;
   const float* dres;  // added to dx (residual branch), nullable
+  int store_mode;     // layer-gradient stores: 0 plain, 1 non-temporal
+  // ---- filled by launch_chain_bwd: weight packs in execution order for the loader wave
+  int nseq;
+  const float4* wseq[kMaxStages + 2];
 };
 
 // prepack table ---------------------------------------------------------------------------------

@@ -52,7 +52,7 @@ __device__ __forceinline__ void load_rows(f32x4 (&v)[NB], const float* row, int 
 }
 
 template <int NB, bool ACCUM>
-__device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* row, int g) {
+__device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* row, int g, int mode = 0) {
   if (!row) return;
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
@@ -62,7 +62,13 @@ __device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* row, int
       const float4 o = *p;
       x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
     }
-    *p = x;
+    if (mode == 1) {
+      __builtin_nontemporal_store(v[t], reinterpret_cast<f32x4*>(p));
+    } else if (mode == 2) {
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v[t]) : "memory");
+    } else {
+      *p = x;
+    }
   }
 }
 
@@ -91,34 +97,85 @@ __device__ __forceinline__ float row_sum(const f32x4 (&v)[NB]) {
 // (32 input features x all outputs) stream L2 -> registers -> LDS ring; one __syncthreads per chunk.
 // Two accumulators are interleaved so back-to-back MFMAs are independent (40-cycle dependent latency vs
 // 32-cycle issue).  All waves of the workgroup must call this together.
+// ---------------------------------------------------------------------------- weight streaming
+// Workgroup = 4 compute waves + 1 LOADER wave.  The loader streams the weight packs of all stages of the
+// kernel, chunk by chunk (a chunk = 32 input features x all outputs, 16 KB at D = 128), from L2 into a 2-deep
+// LDS ring, always one chunk ahead of the compute waves and straight across stage boundaries; with a stage's
+// first chunk it also drops the stage's bias into LDS.  One workgroup barrier per chunk.
+//
+// Why a separate wave: vmcnt retires loads and stores through one in-order counter and hipcc waits vmcnt(0)
+// whenever both kinds are outstanding, so a compute wave that fetched its own weights would stop at every chunk
+// until its activation stores had reached memory -- MFMA phases and HBM phases then add up instead of
+// overlapping (measured: kernel time = MFMA time + store time).  Compute waves execute NO vmcnt wait in the
+// steady state; their stores drain in the background.
 template <int NB>
-__device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], const float4* __restrict__ wp,
-                                           float4* lds, int tid, int lane) {
-  constexpr int KB_PER = NB >= 2 ? 2 : 1;        // 16-feature k blocks per chunk
-  constexpr int NCH = NB / KB_PER;               // chunks per stage
-  constexpr int CH = KB_PER * NB * 64;           // float4 per chunk
-  constexpr int PER = CH / 256;                  // float4 per thread per chunk
-  static_assert(CH % 256 == 0, "chunk must be a whole number of float4 per thread");
-  float4 st[PER];
+struct Ring {
+  static constexpr int KB_PER = NB >= 2 ? 2 : 1;  // 16-feature k blocks per chunk
+  static constexpr int NCH = NB / KB_PER;         // chunks per stage
+  static constexpr int CH = KB_PER * NB * 64;     // float4 per chunk
+  static constexpr int D = NB * 16;
+  static constexpr size_t lds_bytes = size_t(2) * CH * sizeof(float4) + size_t(2) * D * sizeof(float);
+  static_assert(CH % 64 == 0, "chunk must be a whole number of float4 per loader lane");
+};
+
+// workgroup barrier that waits for LDS traffic only (never for vmcnt)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NB>
+__device__ __forceinline__ float* ring_bias(float4* lds, int stage) {
+  return reinterpret_cast<float*>(lds + 2 * Ring<NB>::CH) + (stage & 1) * Ring<NB>::D;
+}
+
+// the loader wave's whole life
+template <int NB>
+__device__ __forceinline__ void loader_run(const float4* const* wseq, const float* const* bseq, int nseq, float4* lds,
+                                           int lane) {
+  using R = Ring<NB>;
+  constexpr int ROUND = 16;                        // float4 per lane per round (64 VGPRs)
+  constexpr int PER = R::CH / 64;                  // float4 per lane per chunk
+  int j = 0;
+  for (int s = 0; s < nseq; ++s) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wseq[s]);
+    for (int c = 0; c < R::NCH; ++c, ++j) {
+      f32x4* dst = reinterpret_cast<f32x4*>(lds) + (j & 1) * R::CH;
+      const f32x4* src = wp + c * R::CH;
 #pragma unroll
-  for (int i = 0; i < PER; ++i)
-    st[i] = wp[i * 256 + tid];
+      for (int r0 = 0; r0 < PER; r0 += ROUND) {
+        f32x4 v[ROUND];
 #pragma unroll
-  for (int i = 0; i < PER; ++i)
-    lds[i * 256 + tid] = st[i];
-  __syncthreads();
+        for (int i = 0; i < ROUND; ++i)
+          if (r0 + i < PER) v[i] = src[(r0 + i) * 64 + lane];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const float4* cur = lds + (c & 1) * CH;
-    float4* nxt = lds + ((c + 1) & 1) * CH;
-    if (c + 1 < NCH) {
-#pragma unroll
-      for (int i = 0; i < PER; ++i)
-        st[i] = wp[(c + 1) * CH + i * 256 + tid];
+        for (int i = 0; i < ROUND; ++i)
+          if (r0 + i < PER) dst[(r0 + i) * 64 + lane] = v[i];
+      }
+      if (c == 0 && bseq && bseq[s]) {
+        float* bl = ring_bias<NB>(lds, s);
+        for (int f = lane; f < R::D; f += 64) bl[f] = bseq[s][f];
+      }
+      lds_barrier();                               // publishes chunk j (compute waves arrive after chunk j-1)
     }
+  }
+  lds_barrier();                                   // pairs with the compute waves' barrier after the last chunk
+}
+
+// One Linear on the compute waves: acc[t] += sum_kb W(kb,t) * act[kb] with v_mfma_f32_16x16x4_f32.  The A operand
+// of step s is the weight fragment W[16t + (l&15)][16kb + 4g + s] (lane-linear ds_read_b128 from the ring), the B
+// operand this lane's own act[kb][s].  `j` = running chunk counter (ring slot = j & 1).  Two accumulators are
+// interleaved so back-to-back MFMAs are independent (40-cycle dependent latency vs 32-cycle issue).
+// `store_row` (nullable): this lane's row of an HBM tensor that receives `act`; issued with the first chunk so the
+// store has the whole stage to drain.
+template <int NB>
+__device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& j, int lane,
+                                           float* store_row = nullptr, int store_mode = 0) {
+  using R = Ring<NB>;
+  store_rows<NB, false>(act, store_row, lane >> 4, store_mode);
 #pragma unroll
-    for (int kk = 0; kk < KB_PER; ++kk) {
-      const int kb = c * KB_PER + kk;
+  for (int c = 0; c < R::NCH; ++c) {
+    const float4* cur = lds + ((j + c) & 1) * R::CH;
+#pragma unroll
+    for (int kk = 0; kk < R::KB_PER; ++kk) {
+      const int kb = c * R::KB_PER + kk;
 #pragma unroll
       for (int t = 0; t < NB; t += 2) {
         const float4 w0 = cur[(kk * NB + t) * 64 + lane];
@@ -133,12 +190,23 @@ __device__ __forceinline__ void gemm_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
         if (t + 1 < NB) acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, act[kb][3], acc[t + 1], 0, 0, 0);
       }
     }
-    if (c + 1 < NCH) {
+    lds_barrier();
+  }
+  j += R::NCH;
+}
+
+// acc = bias of sequence entry `stage` (from the ring) or 0
+template <int NB>
+__device__ __forceinline__ void init_acc(f32x4 (&acc)[NB], float4* lds, int stage, bool has_bias, int lg) {
+  if (has_bias) {
+    const float* bl = ring_bias<NB>(lds, stage);
 #pragma unroll
-      for (int i = 0; i < PER; ++i)
-        nxt[i * 256 + tid] = st[i];
+    for (int t = 0; t < NB; ++t) {
+      const float4 x = *reinterpret_cast<const float4*>(bl + 16 * t + 4 * lg);
+      acc[t] = f32x4{x.x, x.y, x.z, x.w};
     }
-    __syncthreads();
+  } else {
+    zero_tile<NB>(acc);
   }
 }
 
@@ -179,10 +247,14 @@ __device__ __forceinline__ float dot_features(const f32x4 (&v)[NB], const float*
 
 // -------------------------------------------------------------------------------- forward chain
 template <int NB, int IN, int OUT>
-__global__ __launch_bounds__(256) void k_chain_fwd(ChainFwdArgs a) {
+__global__ __launch_bounds__(kChainThreads) void k_chain_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
+  if (wave == 4) {  // loader wave (uniform branch)
+    loader_run<NB>(a.wseq, a.bseq, a.nseq, lds, lane);
+    return;
+  }
   const int64_t row = int64_t(blockIdx.x) * kTileRows + wave * 16 + (lane & 15);
   const bool live = row < a.R;
 
@@ -196,7 +268,6 @@ __global__ __launch_bounds__(256) void k_chain_fwd(ChainFwdArgs a) {
       load_features<NB>(act, a.bias_in, lg);
       for (int k = 0; k < a.K0; ++k) axpy_features<NB>(act, a.w0t + k * D, a.x[row * a.K0 + k], lg);
       relu_into<NB>(act, act);
-      store_rows<NB, false>(act, a.store_in ? a.store_in + row * D : nullptr, lg);
     } else {
       zero_tile<NB>(act);
     }
@@ -217,25 +288,31 @@ __global__ __launch_bounds__(256) void k_chain_fwd(ChainFwdArgs a) {
       }
       axpy_features<NB>(act, a.w0t + a.p * D, sqrtf(n2), lg);
       relu_into<NB>(act, act);
-      store_rows<NB, false>(act, a.store_in ? a.store_in + row * D : nullptr, lg);
     } else {
       zero_tile<NB>(act);
     }
   }
 
-  // ---- MFMA stages
+  // ---- MFMA stages.  The activation entering a stage is stored to HBM from inside that stage (mfma_stage).
+  int j = 0, sq = 0;  // ring chunk counter, index into the loader's weight sequence
+  lds_barrier();      // chunk 0 (+ bias of the first stage) is in the ring
+  float* pending = ((IN == IN_SMALL || IN == IN_EDGE) && live && a.store_in) ? a.store_in + row * D : nullptr;
+  if (a.nstage == 0 && pending) store_rows<NB, false>(act, pending, lg);
   for (int l = 0; l < a.nstage; ++l) {
-    if (a.bias[l]) load_features<NB>(acc, a.bias[l], lg);
-    else zero_tile<NB>(acc);
-    gemm_stage<NB>(acc, act, a.wp[l], lds, tid, lane);
+    init_acc<NB>(acc, lds, sq, a.bias[l] != nullptr, lg);
+    mfma_stage<NB>(acc, act, lds, j, lane, pending, a.store_mode);
+    ++sq;
+    pending = nullptr;
     if (IN == IN_ROWS2 && l == 0) {
       load_rows<NB>(act, live ? a.x2 + row * D : nullptr, lg);
-      gemm_stage<NB>(acc, act, a.wp0b, lds, tid, lane);
+      mfma_stage<NB>(acc, act, lds, j, lane);
+      ++sq;
     }
     const bool last = (l == a.nstage - 1);
     if (!last || OUT == OUT_SMALL) {
       relu_into<NB>(act, acc);
-      if (live && a.store[l]) store_rows<NB, false>(act, a.store[l] + row * D, lg);
+      if (!last) pending = (live && a.store[l]) ? a.store[l] + row * D : nullptr;
+      else if (live && a.store[l]) store_rows<NB, false>(act, a.store[l] + row * D, lg);
     }
   }
   if (!live) return;
@@ -264,7 +341,7 @@ __global__ __launch_bounds__(256) void k_chain_fwd(ChainFwdArgs a) {
 #pragma unroll
       for (int t = 0; t < NB; ++t) acc[t] += act[t];
     }
-    store_rows<NB, false>(acc, a.y + row * D, lg);
+    store_rows<NB, false>(acc, a.y + row * D, lg, a.out_mode);
   } else if (OUT == OUT_PLAIN) {
     if (a.accumulate) store_rows<NB, true>(acc, a.y + row * D, lg);
     else store_rows<NB, false>(acc, a.y + row * D, lg);
@@ -290,10 +367,14 @@ __device__ __forceinline__ void mask_by(f32x4 (&gr)[NB], const float* act_row, i
 }
 
 template <int NB, int GIN, int FIRST>
-__global__ __launch_bounds__(256) void k_chain_bwd(ChainBwdArgs a) {
+__global__ __launch_bounds__(kChainThreads) void k_chain_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
+  if (wave == 4) {  // loader wave (uniform branch)
+    loader_run<NB>(a.wseq, nullptr, a.nseq, lds, lane);
+    return;
+  }
   const int64_t row = int64_t(blockIdx.x) * kTileRows + wave * 16 + (lane & 15);
   const bool live = row < a.R;
 
@@ -327,44 +408,60 @@ __global__ __launch_bounds__(256) void k_chain_bwd(ChainBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) g[t][r] = rs * (g[t][r] - m1 - acc[t][r] * m2);
     }
-    if (a.gstore[0]) store_rows<NB, false>(g, a.gstore[0] + row * D, lg);
   }
+  // The gradient entering a stage is stored to HBM from inside that stage (mfma_stage), so the store has a whole
+  // stage to drain before the next vmcnt wait (the ReLU-mask rows at the end of the stage).
+  int j = 0;
+  lds_barrier();      // chunk 0 is in the ring
+  float* pending = (live && a.gstore[0]) ? a.gstore[0] + row * D : nullptr;
 
   for (int k = 0; k < a.nstage; ++k) {
     zero_tile<NB>(acc);
-    gemm_stage<NB>(acc, g, a.wpt[k], lds, tid, lane);
+    mfma_stage<NB>(acc, g, lds, j, lane, pending, a.store_mode);
+    const bool masked = live && a.mask[k];
+    if (masked) load_rows<NB>(g, a.mask[k] + row * D, lg);            // g is consumed: reuse it for the mask rows
 #pragma unroll
-    for (int t = 0; t < NB; ++t) g[t] = acc[t];
-    if (live) {
-      if (a.mask[k]) mask_by<NB>(g, a.mask[k] + row * D, lg);
-      if (a.gstore[k + 1]) store_rows<NB, false>(g, a.gstore[k + 1] + row * D, lg);
-    }
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[t][r] = (!masked || g[t][r] > 0.f) ? acc[t][r] : 0.f;
+    pending = (live && a.gstore[k + 1]) ? a.gstore[k + 1] + row * D : nullptr;
   }
 
   if (FIRST != F_NONE) {
     zero_tile<NB>(acc);
-    gemm_stage<NB>(acc, g, a.wh0, lds, tid, lane);
-    if (live) {
-      if (a.dres) {
-        f32x4 r[NB];
-        load_rows<NB>(r, a.dres + row * D, lg);
+    mfma_stage<NB>(acc, g, lds, j, lane, pending);
+    pending = nullptr;
+    if (live && a.dres) {
+      f32x4 r[NB];
+      load_rows<NB>(r, a.dres + row * D, lg);
 #pragma unroll
-        for (int t = 0; t < NB; ++t) acc[t] += r[t];
-      }
-      store_rows<NB, false>(acc, a.dx + row * D, lg);
+      for (int t = 0; t < NB; ++t) acc[t] += r[t];
     }
     if (FIRST == F_HEADS2) {
-      zero_tile<NB>(acc);
-      gemm_stage<NB>(acc, g, a.wh1, lds, tid, lane);
-      if (live) store_rows<NB, false>(acc, a.dx2 + row * D, lg);
+      f32x4 acc2[NB];
+      zero_tile<NB>(acc2);
+      mfma_stage<NB>(acc2, g, lds, j, lane);
+      if (live) {
+        store_rows<NB, false>(acc, a.dx + row * D, lg);
+        store_rows<NB, false>(acc2, a.dx2 + row * D, lg);
+      }
+    } else if (live) {
+      store_rows<NB, false>(acc, a.dx + row * D, lg);
     }
   }
+  if (pending) store_rows<NB, false>(g, pending, lg);
 }
 
 template <int NB, int IN, int OUT>
-int launch_fwd_t(const ChainFwdArgs& a, hipStream_t s) {
-  const size_t lds = size_t(2) * (NB >= 2 ? 2 : 1) * NB * 64 * sizeof(float4);
-  hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3((unsigned)ceil_div(a.R, kTileRows)), dim3(256), lds, s, a);
+int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
+  ChainFwdArgs a = a0;
+  a.nseq = 0;
+  for (int l = 0; l < a.nstage; ++l) {  // the loader follows exactly the compute waves' stage order
+    a.wseq[a.nseq] = a.wp[l]; a.bseq[a.nseq++] = a.bias[l];
+    if (IN == IN_ROWS2 && l == 0) { a.wseq[a.nseq] = a.wp0b; a.bseq[a.nseq++] = nullptr; }
+  }
+  const size_t lds = Ring<NB>::lds_bytes;
+  hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3((unsigned)ceil_div(a.R, kTileRows)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -385,9 +482,14 @@ int launch_fwd_n(int in_mode, int out_mode, const ChainFwdArgs& a, hipStream_t s
 }
 
 template <int NB, int GIN, int FIRST>
-int launch_bwd_t(const ChainBwdArgs& a, hipStream_t s) {
-  const size_t lds = size_t(2) * (NB >= 2 ? 2 : 1) * NB * 64 * sizeof(float4);
-  hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3((unsigned)ceil_div(a.R, kTileRows)), dim3(256), lds, s, a);
+int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
+  ChainBwdArgs a = a0;
+  a.nseq = 0;
+  for (int k = 0; k < a.nstage; ++k) a.wseq[a.nseq++] = a.wpt[k];
+  if (FIRST != F_NONE) a.wseq[a.nseq++] = a.wh0;
+  if (FIRST == F_HEADS2) a.wseq[a.nseq++] = a.wh1;
+  const size_t lds = Ring<NB>::lds_bytes;
+  hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3((unsigned)ceil_div(a.R, kTileRows)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }

@@ -11,6 +11,8 @@
 //   node chain         [x, aggr] -> MLP -> LayerNorm -> + x
 // GMP backward mirrors it: node chain bwd -> edge chain bwd -> segment sums of the edge gradient by
 // source and by target -> all weight gradients in one batched split-K launch -> input gradient.
+#include <cstdlib>
+
 #include "chain.h"
 
 using namespace bsms;
@@ -34,6 +36,9 @@ struct Carver {  // identical walk for size queries (base == nullptr) and real b
 };
 
 bool supported_D(int64_t D) { return D == 32 || D == 64 || D == 128 || D == 256; }
+
+static int env_flags() { const char* e = getenv("BSMS_DEBUG_FLAGS"); return e ? atoi(e) : 0; }
+int g_debug_flags = env_flags();  // experiments only: bit0 skip fwd activation stores, bit1 plain (not nt) stores, bit2 nt final y
 
 void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, int K, int kind, float* dst) {
   PackDesc& d = t.d[t.n++];
@@ -104,6 +109,8 @@ int check_gmp(const bsms_plan_t* plan, int64_t B, int64_t D, int64_t p, int H, c
 }  // namespace
 
 // =================================================================================== GMP entries
+extern "C" void bsms_debug_set_flags(int flags) { g_debug_flags = flags; }  // not in bsms_hip.h: experiments only
+
 extern "C" size_t bsms_gmp_saved_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden) {
   if (hidden < 1 || hidden >= kMaxStages) return 0;
   return carve_gmp_saved(nullptr, B, N, E, D, hidden).bytes;
@@ -170,6 +177,12 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
       a.store[st] = (st < H - 1) ? sv.e_act[st + 1] : nullptr;
     }
     a.y = sv.e_y; a.rstd = sv.e_rstd;
+    a.store_mode = (g_debug_flags & 2) ? 0 : 1;   // saved activations are streamed with non-temporal stores
+    a.out_mode = (g_debug_flags & 4) ? 1 : 0;
+    if (g_debug_flags & 1) {
+      a.store_in = nullptr;
+      for (int st = 0; st < H; ++st) a.store[st] = nullptr;
+    }
     if ((rc = launch_chain_fwd((int)D, IN_EDGE, OUT_LN, a, s))) return rc;
   }
   // aggregation (scatter_sum over targets, ops/basic.py:94)
@@ -187,6 +200,7 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
       a.store[st] = (st < H) ? sv.n_act[st] : nullptr;
     }
     a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x;
+    a.store_mode = 1;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_LN, a, s))) return rc;
   }
   return BSMS_OK;
@@ -211,7 +225,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
   // node MLP backward: grad_x = grad_out (residual) + g0 W0x ; daggr = g0 W0a
   {
     ChainBwdArgs a{};
-    a.R = B * N; a.dy = grad_out; a.yln = sv.n_yln; a.rstd = sv.n_rstd;
+    a.R = B * N; a.dy = grad_out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.store_mode = 1;
     a.nstage = H;
     a.gstore[0] = wk.gN[H];
     for (int k = 0; k < H; ++k) {
@@ -227,7 +241,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
   // edge MLP backward (gradient of the aggregation = gather by target)
   {
     ChainBwdArgs a{};
-    a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd;
+    a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd; a.store_mode = (g_debug_flags & 2) ? 0 : 1;
     a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
     a.nstage = H;
     a.gstore[0] = wk.gE[H];
