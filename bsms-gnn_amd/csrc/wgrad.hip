@@ -27,7 +27,7 @@ struct WgradTable {
   float* colsums;    // [tiles][TB]
 };
 
-__global__ __launch_bounds__(256) void k_wgrad(WgradTable tab) {
+__global__ __launch_bounds__(512) void k_wgrad(WgradTable tab) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][G|A][RC][TB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
   int j = 0;
@@ -41,13 +41,14 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradTable tab) {
   const int nchunk = int((r1 - r0 + RC - 1) / RC);
   const int n0 = bi * TB, k0 = bj * TB;
 
-  // staging: each thread moves 4 float4 of G and 4 of A per chunk (row = tid/32 + 8 i, col4 = tid%32)
+  // staging: 512 threads move one 32-row chunk of G and of A (2 x 16 KB): 2 float4 of each per thread
+  // (row = tid/32 + 16 i, col4 = tid%32) -- full 512-byte row bursts
   const int srow = tid >> 5, scol = (tid & 31) * 4;
-  float4 sg[4], sa[4];
+  float4 sg[2], sa[2];
   auto fetch = [&](int chunk) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t r = r0 + int64_t(chunk) * RC + srow + 8 * i;
+    for (int i = 0; i < 2; ++i) {
+      const int64_t r = r0 + int64_t(chunk) * RC + srow + 16 * i;
       const bool rv = r < r1;
       sg[i] = (rv && n0 + scol < D) ? *reinterpret_cast<const float4*>(job.G + r * job.ldg + n0 + scol)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -59,20 +60,20 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradTable tab) {
     float* g = lds + buf * (2 * RC * TB);
     float* a = g + RC * TB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(g + (srow + 8 * i) * TB + scol) = sg[i];
-      *reinterpret_cast<float4*>(a + (srow + 8 * i) * TB + scol) = sa[i];
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(g + (srow + 16 * i) * TB + scol) = sg[i];
+      *reinterpret_cast<float4*>(a + (srow + 16 * i) * TB + scol) = sa[i];
     }
   };
 
-  const int wr = wave >> 1, wc = wave & 1;  // wave owns dW rows [64 wr, +64) x cols [64 wc, +64)
-  f32x16 acc[2][2];
+  // 8 waves: wave owns dW rows [32 wr, +32) x cols [64 wc, +64)  (LDS allows 2 workgroups per CU, so 8 waves per
+  // workgroup = 4 waves per SIMD to cover the LDS-read and barrier latencies)
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
   float csum = 0.f;  // thread tid < TB sums column tid of the G tile
 
   if (nchunk > 0) {
@@ -87,12 +88,10 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradTable tab) {
 #pragma unroll
     for (int s = 0; s < RC / 2; ++s) {
       const int rr = 2 * s + hh;
-      const float a0 = g[rr * TB + 64 * wr + l31], a1 = g[rr * TB + 64 * wr + 32 + l31];
+      const float a0 = g[rr * TB + 32 * wr + l31];
       const float b0 = a[rr * TB + 64 * wc + l31], b1 = a[rr * TB + 64 * wc + 32 + l31];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
     }
     if (job.db && bj == 0 && tid < TB) {
 #pragma unroll 8
@@ -104,14 +103,12 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradTable tab) {
 
   float* part = tab.partials + int64_t(blockIdx.x) * (TB * TB);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        part[n * TB + 64 * wc + 32 * jj + l31] = acc[i][jj][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      part[n * TB + 64 * wc + 32 * jj + l31] = acc[jj][r];
+    }
   if (job.db && bj == 0 && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = csum;
 }
 
@@ -321,7 +318,7 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   tab.partials = reinterpret_cast<float*>(work);
   tab.colsums = tab.partials + size_t(kMaxTiles) * TB * TB;
   const size_t lds = size_t(2) * 2 * RC * TB * sizeof(float);
-  hipLaunchKernelGGL(k_wgrad, dim3(first), dim3(256), lds, s, tab);
+  hipLaunchKernelGGL(k_wgrad, dim3(first), dim3(512), lds, s, tab);
   BSMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div((D * D + D) / 4, 64), njobs), dim3(256), 0, s, tab);
   BSMS_LAUNCH_CHECK();
