@@ -170,6 +170,25 @@ def roofline_objects(wl, batch):
     return roof, mf
 
 
+def rollout_rate(sim, wl, steps=60):
+    """Secondary figure: forward-only autoregressive rollout, batch 1 like the reference
+    (rollout.py:48), inference mode; eager launches vs one captured HIP graph per step."""
+    import bsms_gnn_amd as eng
+    c = wl["cfg"]["out_dim"]
+    ic, mask = wl["node_in"][:1].contiguous(), wl["mask"][:1].contiguous()
+    g1, i1 = [g[:1] for g in wl["m_gs"]], [i[:1] for i in wl["m_ids"]]
+    out = {"batch": 1, "steps": steps, "unit": "rollout steps/s (forward only)"}
+    for name, use_graph in (("eager", False), ("hip_graph", True)):
+        res = torch.zeros(steps, ic.shape[1], c, device="cuda")
+        eng.rollout_one_traj(sim, ic, res[:3], mask, g1, i1, use_graph=use_graph)       # warm-up (+ capture)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.rollout_one_traj(sim, ic, res, mask, g1, i1, use_graph=use_graph)
+        torch.cuda.synchronize()
+        out[name] = steps / (time.perf_counter() - t0)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +263,7 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             line["roofline"], line["roofline_mfma"] = roofline_objects(wl, args.batch)
+            line["rollout"] = rollout_rate(sim, wl)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.batch)
         print(json.dumps(line))

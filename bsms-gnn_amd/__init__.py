@@ -8,5 +8,7 @@ from .model import BSMS_Simulator, Normalizer, masked_rmse, masked_se_sums  # no
 from .ops import BSGMP, GMP, MLP, Unpool, WeightedEdgeConv, degree, scatter_sum  # noqa: F401
 from .dp import DataParallel, GradBuckets, global_masked_rmse  # noqa: F401
 from .hierarchy import BistrideMultiLayerGraph, to_flat_edge  # noqa: F401
+from .rollout import rollout_one_traj, rollout_rmse  # noqa: F401
+from .trainer import FusedAdamW, Trainer, WarmupCosineDecay  # noqa: F401
 
 __version__ = "0.1.0"

@@ -40,6 +40,9 @@ SIGNATURES = {
                              c_void_p, c_void_p]),
     "bsms_gmp_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
                              c_void_p, c_void_p, PP, c_void_p]),
+    "bsms_adamw_work_bytes": (c_size_t, []),
+    "bsms_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_float, c_i64, C.c_float, c_void_p, c_void_p, c_void_p]),
 }
 
 _ERRORS = {-1: "BSMS_E_INVALID_ARG", -2: "BSMS_E_SHAPE", -3: "BSMS_E_UNSUPPORTED", -4: "BSMS_E_HIP"}

@@ -54,22 +54,28 @@ struct GmpSaved {
   float *n_w0x, *n_w0a, *n_w[kMaxStages], *n_wt[kMaxStages], *n_w0xt, *n_w0at;
   size_t bytes;
 };
-GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H) {
+// training = true: everything the backward needs.  training = false (inference, `saved` == NULL at the ABI):
+// only the messages, the aggregate and the forward packs, carved from the scratch buffer instead.
+GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H, bool training = true) {
   Carver c(base);
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = size_t(D) * D;
-  for (int l = 0; l < H; ++l) s.e_act[l] = c.take(re * D);
+  if (training)
+    for (int l = 0; l < H; ++l) s.e_act[l] = c.take(re * D);
   s.e_y = c.take(re * D);
-  s.e_rstd = c.take(re);
+  if (training) s.e_rstd = c.take(re);
   s.aggr = c.take(rn * D);
-  for (int l = 0; l < H; ++l) s.n_act[l] = c.take(rn * D);
-  s.n_yln = c.take(rn * D);
-  s.n_rstd = c.take(rn);
+  if (training) {
+    for (int l = 0; l < H; ++l) s.n_act[l] = c.take(rn * D);
+    s.n_yln = c.take(rn * D);
+    s.n_rstd = c.take(rn);
+  }
   s.e_wi = c.take(dd); s.e_wj = c.take(dd); s.e_wft = c.take(size_t(8) * D);
-  s.e_wit = c.take(dd); s.e_wjt = c.take(dd);
-  for (int l = 1; l <= H; ++l) { s.e_w[l] = c.take(dd); s.e_wt[l] = c.take(dd); }
-  s.n_w0x = c.take(dd); s.n_w0a = c.take(dd); s.n_w0xt = c.take(dd); s.n_w0at = c.take(dd);
-  for (int l = 1; l <= H; ++l) { s.n_w[l] = c.take(dd); s.n_wt[l] = c.take(dd); }
+  if (training) { s.e_wit = c.take(dd); s.e_wjt = c.take(dd); }
+  for (int l = 1; l <= H; ++l) { s.e_w[l] = c.take(dd); if (training) s.e_wt[l] = c.take(dd); }
+  s.n_w0x = c.take(dd); s.n_w0a = c.take(dd);
+  if (training) { s.n_w0xt = c.take(dd); s.n_w0at = c.take(dd); }
+  for (int l = 1; l <= H; ++l) { s.n_w[l] = c.take(dd); if (training) s.n_wt[l] = c.take(dd); }
   s.bytes = c.off;
   return s;
 }
@@ -125,33 +131,39 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
                             void* work, bsms_stream_t stream) {
   int rc = check_gmp(plan, B, D, p, H, "gmp_fwd");
   if (rc) return rc;
-  BSMS_REQUIRE(x && pos && params && out && saved && work, BSMS_E_INVALID_ARG, "gmp_fwd: null argument");
+  BSMS_REQUIRE(x && pos && params && out && work, BSMS_E_INVALID_ARG, "gmp_fwd: null argument");
   hipStream_t s = as_stream(stream);
   const int64_t N = plan->N, E = plan->E;
   const int nl = H + 1;
   const float* const* pn = params;            // mlp_node: W_l = pn[2l], b_l = pn[2l+1]
   const float* const* pe = params + 2 * nl;   // mlp_edge
   const int ldE0 = int(2 * D + p + 1);
-  GmpSaved sv = carve_gmp_saved(saved, B, N, E, D, H);
+  const bool training = saved != nullptr;     // saved == NULL: inference, nothing is kept for a backward
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
+  GmpSaved sv = training ? carve_gmp_saved(saved, B, N, E, D, H, true)
+                         : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false);  // lives in the gradient scratch
 
   PackTable t{};
   add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG, sv.e_wi);
   add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG, sv.e_wj);
   add_pack(t, pe[0], ldE0, 0, 0, (int)D, int(p + 1), PACK_TRANSPOSE, sv.e_wft);
-  add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG_T, sv.e_wit);
-  add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG_T, sv.e_wjt);
+  if (training) {
+    add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG_T, sv.e_wit);
+    add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG_T, sv.e_wjt);
+  }
   for (int l = 1; l <= H; ++l) {
     add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.e_w[l]);
-    add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]);
+    if (training) add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]);
   }
   add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x);
   add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG, sv.n_w0a);
-  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_w0xt);
-  add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG_T, sv.n_w0at);
+  if (training) {
+    add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_w0xt);
+    add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG_T, sv.n_w0at);
+  }
   for (int l = 1; l <= H; ++l) {
     add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w[l]);
-    add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_wt[l]);
+    if (training) add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_wt[l]);
   }
   if ((rc = launch_prepack(t, s))) return rc;
 
@@ -174,7 +186,7 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
     for (int st = 0; st < H; ++st) {
       a.wp[st] = reinterpret_cast<const float4*>(sv.e_w[st + 1]);
       a.bias[st] = pe[2 * (st + 1) + 1];
-      a.store[st] = (st < H - 1) ? sv.e_act[st + 1] : nullptr;
+      a.store[st] = (training && st < H - 1) ? sv.e_act[st + 1] : nullptr;
     }
     a.y = sv.e_y; a.rstd = sv.e_rstd;
     a.store_mode = (g_debug_flags & 2) ? 0 : 1;   // saved activations are streamed with non-temporal stores
@@ -193,11 +205,11 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
     a.R = B * N; a.x = x; a.x2 = sv.aggr; a.nstage = H + 1;
     a.wp[0] = reinterpret_cast<const float4*>(sv.n_w0x);
     a.wp0b = reinterpret_cast<const float4*>(sv.n_w0a);
-    a.bias[0] = pn[1]; a.store[0] = sv.n_act[0];
+    a.bias[0] = pn[1]; a.store[0] = training ? sv.n_act[0] : nullptr;
     for (int st = 1; st <= H; ++st) {
       a.wp[st] = reinterpret_cast<const float4*>(sv.n_w[st]);
       a.bias[st] = pn[2 * st + 1];
-      a.store[st] = (st < H) ? sv.n_act[st] : nullptr;
+      a.store[st] = (training && st < H) ? sv.n_act[st] : nullptr;
     }
     a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x;
     a.store_mode = 1;
@@ -309,13 +321,15 @@ struct MlpSaved {
   float *w[kMaxStages + 1], *wt[kMaxStages + 1], *w0t;
   size_t bytes;
 };
-MlpSaved carve_mlp_saved(void* base, int64_t R, int64_t D, int H) {
+MlpSaved carve_mlp_saved(void* base, int64_t R, int64_t D, int H, bool training = true) {
   Carver c(base);
   MlpSaved s{};
-  for (int l = 0; l < H; ++l) s.act[l] = c.take(size_t(R) * D);
-  s.yln = c.take(size_t(R) * D);
-  s.rstd = c.take(size_t(R));
-  for (int l = 0; l <= H; ++l) { s.w[l] = c.take(size_t(D) * D); s.wt[l] = c.take(size_t(D) * D); }
+  if (training) {
+    for (int l = 0; l < H; ++l) s.act[l] = c.take(size_t(R) * D);
+    s.yln = c.take(size_t(R) * D);
+    s.rstd = c.take(size_t(R));
+  }
+  for (int l = 0; l <= H; ++l) { s.w[l] = c.take(size_t(D) * D); if (training) s.wt[l] = c.take(size_t(D) * D); }
   s.w0t = c.take(size_t(16) * D);
   s.bytes = c.off;
   return s;
@@ -362,12 +376,12 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
                             const float* const* params, float* y, void* saved, void* work, bsms_stream_t stream) {
   int rc = check_mlp(R, in_dim, D, out_dim, H, layer_norm, "mlp_fwd");
   if (rc) return rc;
-  BSMS_REQUIRE((x && y && saved) || R == 0, BSMS_E_INVALID_ARG, "mlp_fwd: null argument");
-  BSMS_REQUIRE(params != nullptr, BSMS_E_INVALID_ARG, "mlp_fwd: params is null");
-  (void)work;
+  BSMS_REQUIRE((x && y) || R == 0, BSMS_E_INVALID_ARG, "mlp_fwd: null argument");
+  BSMS_REQUIRE(params != nullptr && (saved != nullptr || work != nullptr), BSMS_E_INVALID_ARG, "mlp_fwd: null argument");
   hipStream_t s = as_stream(stream);
   const MlpKind kind = mlp_kind(in_dim, D, out_dim, layer_norm);
-  MlpSaved sv = carve_mlp_saved(saved, R, D, H);
+  const bool training = saved != nullptr;     // saved == NULL: inference (packs live in `work`)
+  MlpSaved sv = training ? carve_mlp_saved(saved, R, D, H, true) : carve_mlp_saved(work, R, D, H, false);
 
   PackTable t{};
   const int lfirst = (kind == MLP_SMALL_LN) ? 1 : 0;          // first Linear that runs on the MFMA
@@ -375,7 +389,7 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
   if (kind == MLP_SMALL_LN) add_pack(t, params[0], (int)in_dim, 0, 0, (int)D, (int)in_dim, PACK_TRANSPOSE, sv.w0t);
   for (int l = lfirst; l <= llast; ++l) {
     add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.w[l]);
-    add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.wt[l]);
+    if (training) add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.wt[l]);
   }
   if ((rc = launch_prepack(t, s))) return rc;
 
@@ -383,12 +397,12 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
   a.R = R; a.x = x;
   int st = 0;
   if (kind == MLP_SMALL_LN) {
-    a.K0 = (int)in_dim; a.w0t = sv.w0t; a.bias_in = params[1]; a.store_in = sv.act[0];
+    a.K0 = (int)in_dim; a.w0t = sv.w0t; a.bias_in = params[1]; a.store_in = training ? sv.act[0] : nullptr;
   }
   for (int l = lfirst; l <= llast; ++l, ++st) {
     a.wp[st] = reinterpret_cast<const float4*>(sv.w[l]);
     a.bias[st] = params[2 * l + 1];
-    a.store[st] = (l < H) ? sv.act[l] : nullptr;
+    a.store[st] = (training && l < H) ? sv.act[l] : nullptr;
   }
   a.nstage = st;
   a.y = y;
@@ -396,7 +410,7 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
     a.wout = params[2 * H]; a.bout = params[2 * H + 1]; a.C = (int)out_dim;
     return launch_chain_fwd((int)D, IN_ROWS, OUT_SMALL, a, s);
   }
-  a.yln = sv.yln; a.rstd = sv.rstd;
+  a.yln = training ? sv.yln : nullptr; a.rstd = training ? sv.rstd : nullptr;
   return launch_chain_fwd((int)D, kind == MLP_SMALL_LN ? IN_SMALL : IN_ROWS, OUT_LN, a, s);
 }
 

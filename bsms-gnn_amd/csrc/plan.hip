@@ -20,7 +20,7 @@ void set_error(const char* fmt, ...) {
 
 using namespace bsms;
 
-extern "C" int bsms_abi_version(void) { return 1; }
+extern "C" int bsms_abi_version(void) { return 2; }  // 2: saved == NULL selects inference in *_fwd
 extern "C" const char* bsms_last_error(void) { return bsms::g_err; }
 
 namespace {

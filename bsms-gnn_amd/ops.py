@@ -139,7 +139,24 @@ def degree(index: torch.Tensor, num_nodes: Optional[int] = None, dtype: Optional
     return out if dtype in (None, torch.float32) else out.to(dtype)
 
 
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+
+
 # ------------------------------------------------------------------------------------------ MLP
+def _mlp_infer(x, hidden, layer_norm, out_dim, params):
+    """Forward only (`saved` = NULL at the ABI): nothing is written for a backward."""
+    R, in_dim = x.shape
+    D = params[0].shape[0]
+    L = _abi.lib()
+    y = torch.empty(R, out_dim, device=x.device, dtype=x.dtype)
+    work = _workspace(x.device, L.bsms_mlp_work_bytes(R, in_dim, D, out_dim, hidden))
+    pp, keep = _param_ptrs(params)
+    _abi.check(L.bsms_mlp_fwd(x.data_ptr(), R, in_dim, D, out_dim, hidden, int(layer_norm), pp, y.data_ptr(), None,
+                              work.data_ptr(), _stream()), "bsms_mlp_fwd(inference)")
+    return y
+
+
 class _MLPFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, hidden, layer_norm, out_dim, *params):
@@ -203,12 +220,29 @@ class MLP(nn.Module):
     def forward(self, x):
         x = _dev_f32(x, "MLP")
         lead = x.shape[:-1]
-        y = _MLPFunction.apply(x.reshape(-1, x.shape[-1]), self.hidden_layers, self.layer_normalized, self.output_dim,
-                               *self.flat_params())
+        params = self.flat_params()
+        x2 = x.reshape(-1, x.shape[-1])
+        if _needs_grad(x, *params):
+            y = _MLPFunction.apply(x2, self.hidden_layers, self.layer_normalized, self.output_dim, *params)
+        else:
+            y = _mlp_infer(x2, self.hidden_layers, self.layer_normalized, self.output_dim, params)
         return y.view(*lead, self.output_dim)
 
 
 # ------------------------------------------------------------------------------------------ GMP
+def _gmp_infer(x, pos, plan, hidden, params):
+    """Forward only (`saved` = NULL at the ABI): used by rollout / evaluation under torch.no_grad()."""
+    B, N, D = x.shape
+    p = pos.shape[-1]
+    L = _abi.lib()
+    out = torch.empty_like(x)
+    work = _workspace(x.device, L.bsms_gmp_work_bytes(B, N, plan.E, D, hidden))
+    pp, keep = _param_ptrs(params)
+    _abi.check(L.bsms_gmp_fwd(plan.handle, x.data_ptr(), pos.data_ptr(), B, D, p, N * p if pos.dim() == 3 else 0, hidden, pp,
+                              out.data_ptr(), None, work.data_ptr(), _stream()), "bsms_gmp_fwd(inference)")
+    return out
+
+
 class _GMPFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, plan: LevelPlan, hidden, *params):
@@ -269,7 +303,11 @@ class GMP(nn.Module):
             x = x.unsqueeze(0)
         if plan is None:
             plan = plan_for(g, x.shape[-2])
-        y = _GMPFunction.apply(x, pos, plan, self.hidden_layer, *self.mlp_node.flat_params(), *self.mlp_edge.flat_params())
+        params = [*self.mlp_node.flat_params(), *self.mlp_edge.flat_params()]
+        if _needs_grad(x, *params):
+            y = _GMPFunction.apply(x, pos, plan, self.hidden_layer, *params)
+        else:
+            y = _gmp_infer(x, pos, plan, self.hidden_layer, params)
         return y.squeeze(0) if squeeze else y
 
 

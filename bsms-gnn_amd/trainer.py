@@ -1,0 +1,142 @@
+"""Training harness around the hot path, mirroring the reference's `Trainer` (src/trainer/trainer.py) and
+LR schedule (src/utils/basic.py:168-184): masked-RMSE loss, backward, global-norm clip, AdamW, warm-up +
+cosine decay, save / restore.  The optimizer step is ONE fused HIP launch pair over the flat parameter and
+gradient buffers (bsms_adamw_step) instead of ~180 small tensor updates; under data parallelism the gradients
+are all-reduced (dp.py) before it, so every rank applies the identical update."""
+import math
+import os
+
+import torch
+
+from . import _abi
+from .dp import DataParallel
+
+
+class WarmupCosineDecay:
+    """utils/basic.py:168-184: factor = epoch/warmup up to `warmup`, then 0.5 (1 + cos(pi * progress)).
+    Like torch's _LRScheduler the first optimizer step sees epoch 0 (factor 0)."""
+
+    def __init__(self, base_lr, warmup, max_iters):
+        self.base_lr, self.warmup, self.max_iters, self.last_epoch = base_lr, warmup, max_iters, 0
+
+    def factor(self, epoch=None):
+        epoch = self.last_epoch if epoch is None else epoch
+        if epoch <= self.warmup:
+            return epoch * 1.0 / self.warmup
+        return 0.5 * (1 + math.cos(math.pi * (epoch - self.warmup) / (self.max_iters - self.warmup)))
+
+    def lr(self):
+        return self.base_lr * self.factor()
+
+    def step(self):
+        self.last_epoch += 1
+
+
+class FusedAdamW:
+    """AdamW over the flat buffers of a GradBuckets (dp.py).  Parameters are re-pointed into one flat fp32
+    array with the gradient buffer's layout, so clip + update are two kernel launches for the whole model."""
+
+    def __init__(self, grads, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0):
+        self.grads, self.lr, self.betas, self.eps, self.wd, self.max_norm = grads, lr, betas, eps, weight_decay, max_grad_norm
+        flat = torch.empty_like(grads.flat)
+        for p in grads.params:
+            off, n = grads._slot[p]
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view_as(p)
+        self.flat_p = flat
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.step_count = 0
+        self.grad_norm = torch.zeros(1, device=flat.device, dtype=torch.float32)
+        self._work = torch.empty(max(int(_abi.lib().bsms_adamw_work_bytes()), 4), dtype=torch.uint8, device=flat.device)
+
+    def step(self, lr=None):
+        self.step_count += 1
+        b1, b2 = self.betas
+        _abi.check(_abi.lib().bsms_adamw_step(
+            self.flat_p.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            self.flat_p.numel(), float(self.lr if lr is None else lr), b1, b2, self.eps, self.wd, self.step_count,
+            float(self.max_norm), self.grad_norm.data_ptr(), self._work.data_ptr(), torch.cuda.current_stream().cuda_stream),
+            "bsms_adamw_step")
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+
+
+class Trainer:
+    """src/trainer/trainer.py:9-229.  `model_cfg` needs consistent_mesh, accumulation_steps; `opt_cfg` needs
+    peak_lr, weight_decay, warmup_steps, decay_steps, gnorm_clip (configs/opt/default.yaml)."""
+
+    def __init__(self, model, model_cfg, opt_cfg):
+        self.model_cfg, self.opt_cfg = model_cfg, opt_cfg
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.model = model.to(self.device)
+        self.dp = DataParallel(self.model)                       # world size 1: no collective is issued
+        self.optimizer = FusedAdamW(self.dp.grads, lr=opt_cfg.peak_lr, weight_decay=opt_cfg.weight_decay,
+                                    max_grad_norm=opt_cfg.gnorm_clip)
+        self.lr_scheduler = WarmupCosineDecay(opt_cfg.peak_lr, opt_cfg.warmup_steps, opt_cfg.decay_steps)
+        self.train_step = 0
+        self._synced = False
+
+    def move_to_device(self, data):
+        if isinstance(data, (list, tuple)):
+            return [self.move_to_device(d) for d in data]
+        return data.to(self.device)
+
+    def _warming_up(self):
+        return self.train_step < self.model_cfg.accumulation_steps
+
+    def _model_forward(self, data):
+        return self.model(data, self.model_cfg.consistent_mesh, self._warming_up())
+
+    def get_label_mask(self, data):
+        if self.model_cfg.consistent_mesh:
+            return data[1], data[2]
+        return data[0].y, data[0].mask
+
+    def get_pred(self, data):
+        return self._model_forward(self.move_to_device(data))
+
+    def get_loss(self, data):
+        data = self.move_to_device(data)
+        pred = self._model_forward(data)
+        tar, mask = self.get_label_mask(data)
+        se = (pred - tar) ** 2
+        return torch.sqrt((se * mask).sum() / mask.sum() / se.shape[-1])
+
+    def iter(self, data):
+        """One training iteration (trainer.py:134-156): statistics only during warm-up, otherwise
+        fwd + loss + bwd (+ gradient all-reduce) + clip + AdamW + LR schedule."""
+        data = self.move_to_device(data)
+        if self._warming_up():
+            self._model_forward(data)
+            loss = None
+        else:
+            if not self._synced:                                  # merge normaliser statistics once (dp.py)
+                self.dp.sync_normalizers()
+                self._synced = True
+            loss = self.dp.step_loss_backward(data, self.model_cfg.consistent_mesh)
+            self.optimizer.step(self.lr_scheduler.lr())
+            self.lr_scheduler.step()
+        self.train_step += 1
+        return loss
+
+    def save(self, save_dir):
+        os.makedirs(save_dir, exist_ok=True)
+        torch.save(self.model.state_dict(), f"{save_dir}/{self.train_step}_params.pth")     # reference layout
+        torch.save({"opt": self.optimizer.state_dict(), "epoch": self.lr_scheduler.last_epoch, "train_step": self.train_step},
+                   f"{save_dir}/{self.train_step}_opt_state.pth")                           # the reference's TODO
+
+    def restore(self, save_dir, step, restore_opt_state=True):
+        self.model.load_state_dict(torch.load(f"{save_dir}/{step}_params.pth", map_location=self.device))
+        opt_path = f"{save_dir}/{step}_opt_state.pth"
+        if restore_opt_state and os.path.exists(opt_path):
+            st = torch.load(opt_path, map_location=self.device)
+            self.optimizer.load_state_dict(st["opt"])
+            self.lr_scheduler.last_epoch = st["epoch"]
+            self.train_step = st["train_step"]

@@ -108,7 +108,8 @@ int bsms_gather_rows(const float* x, int64_t B, int64_t N, int64_t D, const int6
 /* ---------------------------------------------------------------- A3: MLP -------------------
  * MLP.forward (ops/basic.py:6-23) over R rows: x [R,in_dim] -> y [R,out_dim].  Used for the
  * encoder (in_dim = out_dim_model+1, LN) and decoder (out_dim = C, no LN) of
- * models/model.py:20-22.  Supported shapes: (in_dim <= 8 or in_dim == D) and
+ * models/model.py:20-22.  `saved` = NULL selects INFERENCE (nothing is kept for a backward; `work`
+ * must then be non-NULL).  Supported shapes: (in_dim <= 8 or in_dim == D) and
  * (out_dim == D with layer_norm, or out_dim <= 8 without).  `saved` keeps the activations the backward
  * needs.  need_dx=0 skips the input gradient (encoder input is data). */
 size_t bsms_mlp_saved_bytes(int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int hidden);
@@ -127,7 +128,8 @@ int bsms_mlp_bwd(const float* x, const float* grad_y, int64_t R, int64_t in_dim,
  * x,out [B,N,D]; pos [B,N,p] (pos_batch_stride = N*p) or [N,p] (pos_batch_stride = 0, the
  * `repeat` branch ops/basic.py:87-88); 1 <= p <= 7.  `params`: 2*(hidden+1) pointers of mlp_node
  * followed by 2*(hidden+1) of mlp_edge (state_dict order of a GMP module).  pos gets no gradient
- * (SURVEY.md quirk 5). */
+ * (SURVEY.md quirk 5).  `saved` = NULL in bsms_gmp_fwd selects INFERENCE (rollout, utils/rollout_utils.py:14-64):
+ * no activation is written for a backward, the messages live in `work`. */
 size_t bsms_gmp_saved_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden);
 size_t bsms_gmp_work_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden);
 int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float* pos, int64_t B, int64_t D,
@@ -137,6 +139,17 @@ int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float* pos, cons
                  int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                  const float* const* params, const void* saved, void* work, float* grad_x,
                  float* const* grads, bsms_stream_t stream);
+
+/* ---------------------------------------------------------------- optimizer step ------------
+ * torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.AdamW.step()
+ * (trainer/trainer.py:150-152) fused over ONE flat fp32 array of all trainable parameters (the
+ * data-parallel gradient buffer has the same layout).  `step` counts from 1 (bias correction);
+ * max_grad_norm <= 0 disables clipping; grad_norm_out (device scalar, nullable) receives the
+ * pre-clip global norm.  Decoupled weight decay and bias-corrected moments exactly as torch.optim.AdamW. */
+size_t bsms_adamw_work_bytes(void);
+int bsms_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                    float max_grad_norm, float* grad_norm_out, void* work, bsms_stream_t stream);
 
 #ifdef __cplusplus
 }

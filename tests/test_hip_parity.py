@@ -307,6 +307,30 @@ def test_simulator_step_and_rollout_golden(eng, graphs):
             frames.append(pr[0])
             cur = torch.where(rmask == 0, ic, torch.cat([pr, tail], -1))
     assert rel_err(torch.stack(frames).cpu(), z.t("rollout")) < 5e-5
+    # the product rollout engine (inference mode, HIP-graph replay) reproduces the same frames
+    for use_graph in (False, True):
+        res = torch.zeros(5, 300, 2, device="cuda")
+        eng.rollout_one_traj(sim, ic, res, rmask, g1, i1, use_graph=use_graph)
+        assert rel_err(res.cpu(), z.t("rollout")) < 5e-5, use_graph
+        assert rel_err(res, torch.stack(frames)) < 2e-6, use_graph
+
+
+def test_inference_mode_matches_training_forward(eng, graphs):
+    """`saved` = NULL path (no activation stores) == the autograd forward, bit for bit."""
+    es, _ = graphs.levels("del300")
+    g = dev(es[0])
+    torch.manual_seed(4)
+    gmp = eng.GMP(64, 3, 2).cuda()
+    x, pos = torch.randn(2, 300, 64, device="cuda"), torch.rand(2, 300, 2, device="cuda")
+    y_train = gmp(x.clone().requires_grad_(True), g, pos)
+    with torch.no_grad():
+        y_inf = gmp(x, g, pos)
+    assert torch.equal(y_train.detach(), y_inf)
+    enc = eng.MLP(3, 64, 64, 3, True).cuda()
+    xin = torch.randn(500, 3, device="cuda")
+    with torch.no_grad():
+        y0 = enc(xin)
+    assert torch.equal(enc(xin).detach(), y0)
 
 
 # ------------------------------------------------------------------------------------ A15
