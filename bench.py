@@ -207,11 +207,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the BSMS engine has no CPU path)")
+    backend = os.environ.get("BSMS_DIST_BACKEND", "nccl")       # "gloo": functional check of the N > 1 path on one GPU
+    if os.environ.get("BSMS_FORCE_DEVICE") is not None:
+        local = int(os.environ["BSMS_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import bsms_gnn_amd as eng
@@ -259,7 +265,7 @@ def main():
                                    f"{wl['cfg']['levels']} bi-stride levels, D={wl['cfg']['latent']}, hidden_layer=3, "
                                    f"batch {args.batch} per GPU (global {args.batch * world}), consistent mesh",
                        "levels_N_E": wl["levels"], "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "trainable_params": n_params, "loss": float(loss)},
+                       "trainable_params": n_params, "loss": float(loss.detach())},
         }
         if world == 1 and not args.no_roofline:
             line["roofline"], line["roofline_mfma"] = roofline_objects(wl, args.batch)

@@ -102,3 +102,36 @@ def plan_for(g, num_nodes, ids=None):
 
 def clear_plan_cache():
     _CACHE.clear()
+
+
+class LevelData:
+    """Stand-in for the per-level `torch_geometric.data.Data` the reference datapipe yields for variable
+    meshes (datasets/base.py:325-349): level 0 carries x / y / mask, every level carries `edge_index`, and the
+    kept-node ids ride in `face` (the reference abuses `face` so that PyG offsets them like an index)."""
+
+    def __init__(self, edge_index, num_nodes, face=None, x=None, y=None, mask=None):
+        self.edge_index, self.num_nodes, self.face, self.x, self.y, self.mask = edge_index, num_nodes, face, x, y, mask
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return LevelData(mv(self.edge_index), self.num_nodes, mv(self.face), mv(self.x), mv(self.y), mv(self.mask))
+
+
+def collate_variable_meshes(samples):
+    """What `torch_geometric.loader.DataLoader` (PyG 2.5.3 `Batch`, train.py:50) does to a list of samples, each a
+    list of per-level LevelData: node tensors are concatenated on dim 0, `edge_index` and `face` on the last dim
+    with the CUMULATIVE NUMBER OF NODES OF THAT LEVEL added.  Result: one block-diagonal graph per level, which
+    `BSMS_Simulator.forward(data, consistent_mesh=False, ...)` consumes with a batch axis of 1."""
+    out = []
+    for lvl in range(len(samples[0])):
+        parts = [s[lvl] for s in samples]
+        offs, acc = [], 0
+        for d in parts:
+            offs.append(acc)
+            acc += int(d.num_nodes)
+        cat = lambda ts, dim: None if ts[0] is None else torch.cat(ts, dim)
+        out.append(LevelData(
+            edge_index=torch.cat([d.edge_index + o for d, o in zip(parts, offs)], dim=-1), num_nodes=acc,
+            face=None if parts[0].face is None else torch.cat([d.face + o for d, o in zip(parts, offs)], dim=-1),
+            x=cat([d.x for d in parts], 0), y=cat([d.y for d in parts], 0), mask=cat([d.mask for d in parts], 0)))
+    return out

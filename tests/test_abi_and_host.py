@@ -109,3 +109,25 @@ def test_bench_workload_sizes(eng):
     assert [len(i) for i in m_ids] == [2609, 1263, 591, 236, 70]
     _, m_es, m_ids = build_mesh("cylinder")
     assert [e.shape[1] for e in m_es] == [11264, 9120, 7574, 5628, 3280] and [len(i) for i in m_ids] == [937, 448, 206, 61]
+
+
+def test_product_collate_equals_oracle_collate(eng, graphs):
+    """A15: product block-diagonal collate == the oracle's restatement == the golden hand-built batch."""
+    from conftest import load_golden
+    from oracle import bsms_oracle as ro
+    z = load_golden("blockdiag")
+    samples, osamples = [], []
+    for nm in ("del64", "del300"):
+        es, ids = graphs.levels(nm)
+        n = graphs.np(f"{nm}/pos").shape[0]
+        sizes = [n] + [i.numel() for i in ids[:2]]
+        x = torch.zeros(n, 3)
+        samples.append([eng.LevelData(es[l], sizes[l], face=ids[l] if l < 2 else None, x=x if l == 0 else None) for l in range(3)])
+        osamples.append(dict(x=x, m_gs=es[:3], m_ids=ids[:2]))
+    batch = eng.collate_variable_meshes(samples)
+    _, o_gs, o_ids = ro.collate_block_diagonal(osamples)
+    for l in range(3):
+        assert torch.equal(batch[l].edge_index, o_gs[l]) and torch.equal(batch[l].edge_index, z.t(f"cat/e{l}"))
+    for l in range(2):
+        assert torch.equal(batch[l].face, o_ids[l]) and torch.equal(batch[l].face, z.t(f"cat/ids{l}"))
+    assert batch[2].face is None and batch[0].x.shape[0] == 364

@@ -347,6 +347,39 @@ def test_block_diagonal_batch(eng, graphs):
     assert rel_err(y[0, :64], z.t("del64/y")) < FWD_TOL and rel_err(y[0, 64:], z.t("del300/y")) < FWD_TOL
 
 
+def test_variable_mesh_branch(eng, graphs):
+    """consistent_mesh=False: two DIFFERENT meshes collated block-diagonally (datasets/base.py:325-349 + PyG Batch)
+    through BSMS_Simulator == each mesh alone through the CPU oracle."""
+    cfg = ro.make_cfg(2, 32, 3, 2, 2)
+    torch.manual_seed(5)
+    ref = ro.BSMS_Simulator(cfg)
+    samples, per_sample = [], []
+    for nm in ("del64", "del300"):
+        es, ids = graphs.levels(nm)
+        n = graphs.np(f"{nm}/pos").shape[0]
+        pos = torch.tensor(graphs.np(f"{nm}/pos")[:, :2], dtype=torch.float32)
+        state, ntype = torch.randn(n, 2), (torch.rand(n, 1) < 0.1).float()
+        x, y, mask = torch.cat([state, pos, ntype], -1), state + 0.1 * torch.randn(n, 2), (ntype == 0).float()
+        sizes = [n] + [i.numel() for i in ids[:2]]
+        samples.append([eng.LevelData(es[l], sizes[l], face=ids[l] if l < 2 else None, x=x if l == 0 else None,
+                                      y=y if l == 0 else None, mask=mask if l == 0 else None) for l in range(3)])
+        per_sample.append((x, y, mask, es[:3], ids[:2]))
+    for x, y, mask, es, ids in per_sample:                                  # statistics from both meshes
+        ref((x[None], y[None], mask[None], [e[None] for e in es], [i[None] for i in ids]), True, True)
+    mine = eng.BSMS_Simulator(cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda()
+    batch = [d.to("cuda") for d in eng.collate_variable_meshes(samples)]
+    assert batch[0].num_nodes == 364 and batch[0].x.shape == (364, 5)
+    with torch.no_grad():
+        pred = mine(batch, False, False).cpu()
+        off = 0
+        for x, y, mask, es, ids in per_sample:
+            want = ref((x[None], y[None], mask[None], [e[None] for e in es], [i[None] for i in ids]), True, False)
+            assert rel_err(pred[:, off:off + x.shape[0]], want) < FWD_TOL
+            off += x.shape[0]
+
+
 # ------------------------------------------------------------------------------------ full size
 def test_full_size_properties(eng):
     """BASELINE.json config sizes (airfoil-like, B=8, D=128): size-independent properties."""
