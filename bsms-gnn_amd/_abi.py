@@ -40,6 +40,12 @@ SIGNATURES = {
                              c_void_p, c_void_p]),
     "bsms_gmp_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
                              c_void_p, c_void_p, PP, c_void_p]),
+    "bsms_hierarchy_create": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, PP]),
+    "bsms_hierarchy_destroy": (c_int, [c_void_p]),
+    "bsms_hierarchy_level_nodes": (c_i64, [c_void_p, c_int]),
+    "bsms_hierarchy_level_edges": (c_i64, [c_void_p, c_int]),
+    "bsms_hierarchy_copy_edges": (c_int, [c_void_p, c_int, c_void_p]),
+    "bsms_hierarchy_copy_ids": (c_int, [c_void_p, c_int, c_void_p]),
     "bsms_adamw_work_bytes": (c_size_t, []),
     "bsms_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, c_i64, C.c_float, c_void_p, c_void_p, c_void_p]),

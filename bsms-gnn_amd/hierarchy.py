@@ -91,10 +91,40 @@ def bstride_selection(flat_edge, pos_mesh, n):
     return keep, np.stack([rows[order], cols[order]])
 
 
+def _native_hierarchy(flat_edge, num_layers, num_nodes, pos_mesh):
+    """The C++ builder of libbsms_hip.so (csrc/hierarchy.hip; host code, works without a GPU)."""
+    import ctypes as C
+    from . import _abi
+    L = _abi.lib()
+    coo = np.ascontiguousarray(flat_edge, dtype=np.int64)
+    pos = np.ascontiguousarray(pos_mesh, dtype=np.float64)
+    h = C.c_void_p()
+    _abi.check(L.bsms_hierarchy_create(coo.ctypes.data, coo.shape[1], num_nodes, pos.ctypes.data, pos.shape[1], num_layers,
+                                       C.byref(h)), "bsms_hierarchy_create")
+    try:
+        es, ids = [], []
+        for l in range(num_layers + 1):
+            e = np.empty((2, L.bsms_hierarchy_level_edges(h, l)), dtype=np.int64)
+            _abi.check(L.bsms_hierarchy_copy_edges(h, l, e.ctypes.data), "bsms_hierarchy_copy_edges")
+            es.append(e)
+        for l in range(num_layers):
+            k = np.empty(L.bsms_hierarchy_level_nodes(h, l + 1), dtype=np.int64)
+            _abi.check(L.bsms_hierarchy_copy_ids(h, l, k.ctypes.data), "bsms_hierarchy_copy_ids")
+            ids.append(k)
+    finally:
+        L.bsms_hierarchy_destroy(h)
+    return es, ids
+
+
 class BistrideMultiLayerGraph:
-    def __init__(self, flat_edge, num_layers, num_nodes, pos_mesh):
+    def __init__(self, flat_edge, num_layers, num_nodes, pos_mesh, backend="native"):
+        """backend="native": C++ builder in libbsms_hip.so (default); "scipy": the SciPy-csgraph builder below."""
         self.num_nodes, self.num_layers = num_nodes, num_layers
         self.pos_mesh = np.asarray(pos_mesh)
+        if backend == "native":
+            self.m_flat_es, self.m_ids = _native_hierarchy(np.asarray(flat_edge), num_layers, num_nodes, self.pos_mesh)
+            self.m_flat_es[0] = np.asarray(flat_edge)
+            return
         self.m_flat_es = [np.asarray(flat_edge)]
         self.m_ids = []
         g, pos, n = self.m_flat_es[0], self.pos_mesh, num_nodes

@@ -432,26 +432,44 @@ class BSGMP(nn.Module):
             self.up_gmps.append(GMP(latent_dim, hidden_layer, pos_dim))
             self.unpools.append(Unpool())
 
+    def _edge_weights(self, plans, m_ids, device):
+        """cal_ew chain of the down pass (BSMS.py:64,73,89).  It depends on the MESH only (w starts as ones, runs
+        under no_grad and never sees h or pos), so it is computed once per hierarchy and cached on the level-0 plan;
+        the reference recomputes it in every forward."""
+        key = tuple(id(p) for p in plans)
+        cache = getattr(plans[0], "_ew_chain", None) if plans else None
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        ews = []
+        if plans:
+            w = torch.ones(plans[0].N, device=device, dtype=torch.float32)
+            for plan, ids in zip(plans, m_ids):
+                ew, w_full = self.edge_conv.cal_ew(w, None, plan=plan)
+                w = w_full[ids]
+                ews.append(ew)
+            plans[0]._ew_chain = (key, ews, plans)               # keeps the keyed plans alive -> ids stay unique
+        return ews
+
     def forward(self, h, m_ids, m_gs, pos):
         if h.dim() not in (2, 3) or pos.dim() not in (2, 3):
             raise NotImplementedError("Only implemented for dim 2 and 3")
         h = _dev_f32(h, "BSGMP")
         pos = _dev_f32(pos, "BSGMP")
         L = self.unet_depth
-        skips, skip_pos, ews, plans = [], [], [], []
-        w = torch.ones(pos.shape[-2], device=pos.device, dtype=torch.float32)  # BSMS.py:64
+        skips, skip_pos, plans = [], [], []
+        n_l = h.shape[-2]
+        for i in range(L):                                   # plans first: they fix the level sizes
+            plans.append(plan_for(m_gs[i], n_l, m_ids[i]))
+            n_l = plans[-1].Nk
+        ews = self._edge_weights(plans, m_ids, pos.device)
         for i in range(L):
-            plan = plan_for(m_gs[i], h.shape[-2], m_ids[i])
+            plan = plans[i]
             h = self.down_gmps[i](h, m_gs[i], pos, plan=plan)
             skips.append(h)
             skip_pos.append(pos)
-            ew, w_full = self.edge_conv.cal_ew(w, m_gs[i], plan=plan)
-            h = _edge_conv(h, ew, plan, True, True)          # conv + pool  (BSMS.py:74,79-83)
+            h = _edge_conv(h, ews[i], plan, True, True)          # conv + pool  (BSMS.py:74,79-83)
             with torch.no_grad():
-                pos = _edge_conv(pos, ew, plan, True, True)  # BSMS.py:75,85-88 ; pos carries no gradient
-            w = w_full[m_ids[i]]                             # BSMS.py:89
-            ews.append(ew)
-            plans.append(plan)
+                pos = _edge_conv(pos, ews[i], plan, True, True)  # BSMS.py:75,85-88 ; pos carries no gradient
         h = self.bottom_gmp(h, m_gs[L], pos, plan=plan_for(m_gs[L], h.shape[-2]))
         for i in range(L):
             d = L - 1 - i

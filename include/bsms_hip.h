@@ -140,6 +140,22 @@ int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float* pos, cons
                  const float* const* params, const void* saved, void* work, float* grad_x,
                  float* const* grads, bsms_stream_t stream);
 
+/* ---------------------------------------------------------------- hierarchy builder (host) ---
+ * BistrideMultiLayerGraph (graph_wrappers/bsms_graph_wrapper.py:8-154 + graph_wrapper.py:67-134): the
+ * bi-stride multi-level hierarchy of a mesh, built natively on the HOST (no GPU needed, no SciPy/MKL).
+ * Inputs are HOST pointers: coo int64 [2,E] (level-0 flat edges), pos fp64 [N,pos_dim].  Level l has
+ * level_nodes(l) nodes and level_edges(l) directed edges; copy_edges writes int64 [2,E_l] (level 0: the
+ * caller's edges unchanged; coarser levels row-major with sorted columns), copy_ids writes the kept node
+ * ids of level l (ascending, relative to level l; `m_ids[l]`), bit-exact w.r.t. the reference. */
+typedef struct bsms_hierarchy bsms_hierarchy_t;
+int bsms_hierarchy_create(const int64_t* coo_host, int64_t E, int64_t N, const double* pos_host,
+                          int64_t pos_dim, int num_layers, bsms_hierarchy_t** out);
+int bsms_hierarchy_destroy(bsms_hierarchy_t* h);
+int64_t bsms_hierarchy_level_nodes(const bsms_hierarchy_t* h, int level);
+int64_t bsms_hierarchy_level_edges(const bsms_hierarchy_t* h, int level);
+int bsms_hierarchy_copy_edges(const bsms_hierarchy_t* h, int level, int64_t* out);
+int bsms_hierarchy_copy_ids(const bsms_hierarchy_t* h, int level, int64_t* out);
+
 /* ---------------------------------------------------------------- optimizer step ------------
  * torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.AdamW.step()
  * (trainer/trainer.py:150-152) fused over ONE flat fp32 array of all trainable parameters (the

@@ -87,11 +87,32 @@ def test_product_hierarchy_builder(eng, graphs, name, depth):
     """bsms_gnn_amd.hierarchy (SciPy-accelerated host builder) == golden m_ids bit-exact, coarse edges as sets."""
     es, ids = graphs.levels(name)
     n = graphs.np(f"{name}/pos").shape[0]
-    _, m_es, m_ids = eng.BistrideMultiLayerGraph(es[0].numpy(), depth, n, graphs.np(f"{name}/pos")).get_multi_layer_graphs()
-    for mine, ref in zip(m_ids, ids):
-        assert mine.dtype == np.int64 and np.array_equal(mine, ref.numpy())
-    for mine, ref in zip(m_es, es):
-        assert np.array_equal(bo.canonical_edges(np.asarray(mine)), bo.canonical_edges(ref.numpy()))
+    for backend in ("native", "scipy"):                      # C++ builder in the library and the SciPy one
+        _, m_es, m_ids = eng.BistrideMultiLayerGraph(es[0].numpy(), depth, n, graphs.np(f"{name}/pos"),
+                                                     backend=backend).get_multi_layer_graphs()
+        for mine, ref in zip(m_ids, ids):
+            assert mine.dtype == np.int64 and np.array_equal(mine, ref.numpy()), backend
+        for l, (mine, ref) in enumerate(zip(m_es, es)):
+            want = ref.numpy() if l == 0 else bo.canonical_edges(ref.numpy())      # level 0 keeps the caller's order
+            assert np.array_equal(np.asarray(mine), want), (backend, l)
+
+
+def test_native_hierarchy_directed_and_large(eng):
+    """Directed graph with several components + the bench meshes: native == SciPy builder == oracle."""
+    rng = np.random.default_rng(3)
+    n = 400
+    src, dst = rng.integers(0, n, 900), rng.integers(0, n, 900)
+    keep = src != dst
+    g = np.stack([np.concatenate([src[keep], dst[keep]]), np.concatenate([dst[keep], src[keep]])])
+    g = np.unique(g, axis=1)
+    pos = rng.random((n, 3))
+    a = eng.BistrideMultiLayerGraph(g, 3, n, pos, backend="native")
+    b = eng.BistrideMultiLayerGraph(g, 3, n, pos, backend="scipy")
+    o_es, o_ids = bo.build_hierarchy(g, 3, n, pos)
+    for x, y, z in zip(a.m_ids, b.m_ids, o_ids):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    for l in range(1, 4):
+        assert np.array_equal(a.m_flat_es[l], b.m_flat_es[l]) and np.array_equal(a.m_flat_es[l], bo.canonical_edges(o_es[l]))
 
 
 @pytest.mark.parametrize("name,kind", [("del64", "tri"), ("surf200", "tri"), ("quad", "quad"), ("tetra", "tetra"), ("line", "line")])
