@@ -36,6 +36,18 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 inline hipStream_t as_stream(bsms_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Internal fork/join helper: one non-blocking side stream + two events per device, created lazily and kept for
+// the life of the process.  A fork makes the side stream wait for everything queued on `main` so far; a join makes
+// `main` wait for the side stream.  Stream-wait-event takes a snapshot, so the events are safely reused per call,
+// and both operations are legal inside HIP-graph capture.
+struct SideLane {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+};
+int side_lane(SideLane** out);                       // for the current device
+int side_fork(SideLane* lane, hipStream_t main);     // side waits for main
+int side_join(SideLane* lane, hipStream_t main);     // main waits for side
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 

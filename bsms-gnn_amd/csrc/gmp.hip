@@ -84,7 +84,7 @@ struct GmpWork {
   float *Ps, *Pd;                    // fwd
   float *gN[kMaxStages + 1], *daggr; // bwd
   float *gE[kMaxStages + 1], *dPs, *dPd;
-  char *wg, *sw;
+  char *wg, *wg2, *sw;
   size_t bytes;
 };
 GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H) {
@@ -97,6 +97,7 @@ GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, i
   w.daggr = c.take(rn * D);
   for (int l = 0; l <= H; ++l) w.gE[l] = c.take(re * D);
   w.wg = c.take_bytes(wgrad_work_bytes((int)D, 0));
+  w.wg2 = c.take_bytes(wgrad_work_bytes((int)D, 0));   // second split-K area: two wgrad launches run concurrently
   w.sw = c.take_bytes(small_wgrad_work_bytes((int)D));
   w.bytes = c.off;
   return w;
@@ -264,6 +265,33 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     }
     if ((rc = launch_chain_bwd((int)D, G_EDGE_LN, F_NONE, a, s))) return rc;
   }
+  // From here two independent strands run CONCURRENTLY (fork/join on an internal side stream):
+  //   side: the MFMA-bound batched weight gradients of all D x D layers (reads gE[1..H], gN[*], saved activations)
+  //   main: the HBM-bound strand -- scatter of gE[0] to the two projections, fiber/bias gradients of the first edge
+  //         Linear, the projection weight gradients and finally the input gradient.
+  // They touch disjoint outputs; main joins the side stream before returning, so callers see ordinary semantics.
+  // (Forking the node-layer gradients earlier, against the edge backward chain, measured SLOWER: two MFMA-bound
+  // kernels contend; an MFMA-bound kernel against HBM-bound ones is the pairing that pays: +5.6 % steps/s.)
+  SideLane* lane = nullptr;
+  const bool overlap = !(g_debug_flags & 8);
+  hipStream_t ws = s;
+  if (overlap) {
+    if ((rc = side_lane(&lane)) || (rc = side_fork(lane, s))) return rc;
+    ws = lane->stream;
+  }
+  {
+    WgradJob jobs[kMaxWgradJobs];
+    int nj = 0;
+    auto add_job = [&](const float* G, const float* A, float* dW, float* db, int64_t R, int ldw, int col0) {
+      WgradJob& j = jobs[nj++];
+      j.G = G; j.A = A; j.dW = dW; j.db = db; j.R = R; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldw; j.col0 = col0;
+    };
+    for (int l = 1; l <= H; ++l) add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0);
+    for (int l = 1; l <= H; ++l) add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0);
+    add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0);
+    add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D);
+    if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, ws))) return rc;
+  }
   // gradient of the first edge Linear w.r.t. the two per-node projections
   if ((rc = rowsum_by_source(plan, wk.gE[0], B, D, wk.dPs, s))) return rc;
   if ((rc = rowsum_plan_order(plan, wk.gE[0], B, D, wk.dPd, s))) return rc;
@@ -277,21 +305,15 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     a.R = B * E; a.D = (int)D;
     if ((rc = launch_small_wgrad(a, wk.sw, s))) return rc;
   }
-  // every D x D weight gradient of the block in one batched split-K launch
+  // x-columns of W0_edge (the two projections)
   {
-    WgradJob jobs[kMaxWgradJobs];
-    int nj = 0;
-    auto add = [&](const float* G, const float* A, float* dW, float* db, int64_t R, int ldw, int col0) {
-      WgradJob& j = jobs[nj++];
-      j.G = G; j.A = A; j.dW = dW; j.db = db; j.R = R; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldw; j.col0 = col0;
+    WgradJob jobs[2];
+    auto set = [&](WgradJob& j, const float* G, int col0) {
+      j.G = G; j.A = x; j.dW = ge[0]; j.db = nullptr; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldE0; j.col0 = col0;
     };
-    for (int l = 1; l <= H; ++l) add(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0);
-    add(wk.dPs, x, ge[0], nullptr, B * N, ldE0, int(p + 1));
-    add(wk.dPd, x, ge[0], nullptr, B * N, ldE0, int(p + 1 + D));
-    for (int l = 1; l <= H; ++l) add(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0);
-    add(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0);
-    add(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D);
-    if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, s))) return rc;
+    set(jobs[0], wk.dPs, int(p + 1));
+    set(jobs[1], wk.dPd, int(p + 1 + D));
+    if ((rc = launch_wgrad((int)D, jobs, 2, wk.wg2, s))) return rc;
   }
   // grad_x += dPs Wi + dPd Wj
   {
@@ -302,6 +324,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     a.y = grad_x; a.accumulate = 1;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_PLAIN, a, s))) return rc;
   }
+  if (overlap && (rc = side_join(lane, s))) return rc;
   return BSMS_OK;
 }
 

@@ -3,6 +3,7 @@
 // advanced-indexing gathers x[:, i], x[:, j] (ops/basic.py:70,130).  Built once per mesh level.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -15,6 +16,36 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+}  // namespace bsms
+
+namespace bsms {
+static std::mutex g_lane_mu;
+static SideLane g_lanes[64];
+
+int side_lane(SideLane** out) {
+  int dev = 0;
+  BSMS_HIP_CHECK(hipGetDevice(&dev));
+  BSMS_REQUIRE(dev >= 0 && dev < 64, BSMS_E_UNSUPPORTED, "side_lane: device index %d", dev);
+  std::lock_guard<std::mutex> lock(g_lane_mu);
+  SideLane& l = g_lanes[dev];
+  if (!l.stream) {
+    BSMS_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.fork_ev, hipEventDisableTiming));
+    BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.join_ev, hipEventDisableTiming));
+  }
+  *out = &l;
+  return BSMS_OK;
+}
+int side_fork(SideLane* lane, hipStream_t main) {
+  BSMS_HIP_CHECK(hipEventRecord(lane->fork_ev, main));
+  BSMS_HIP_CHECK(hipStreamWaitEvent(lane->stream, lane->fork_ev, 0));
+  return BSMS_OK;
+}
+int side_join(SideLane* lane, hipStream_t main) {
+  BSMS_HIP_CHECK(hipEventRecord(lane->join_ev, lane->stream));
+  BSMS_HIP_CHECK(hipStreamWaitEvent(main, lane->join_ev, 0));
+  return BSMS_OK;
 }
 }  // namespace bsms
 
