@@ -23,8 +23,9 @@
 namespace bsms {
 
 constexpr int kMaxStages = 8;   // max Linear layers per MLP handled by one chain launch
-constexpr int kTileRows = 64;   // rows of x per workgroup (4 compute waves x 16)
-constexpr int kChainThreads = 320;  // 4 compute waves + 1 loader wave
+constexpr int kComputeWaves = 4;                       // compute waves per workgroup (each owns 16 rows)
+constexpr int kTileRows = kComputeWaves * 16;          // rows of x per workgroup
+constexpr int kChainThreads = (kComputeWaves + 1) * 64;  // + 1 loader wave
 
 enum ChainIn { IN_ROWS = 0, IN_ROWS2 = 1, IN_SMALL = 2, IN_EDGE = 3 };
 enum ChainOut { OUT_LN = 0, OUT_PLAIN = 1, OUT_SMALL = 2 };

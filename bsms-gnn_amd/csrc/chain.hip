@@ -116,6 +116,7 @@ struct Ring {
   static constexpr int D = NB * 16;
   static constexpr size_t lds_bytes = size_t(2) * CH * sizeof(float4) + size_t(2) * D * sizeof(float);
   static_assert(CH % 64 == 0, "chunk must be a whole number of float4 per loader lane");
+  static_assert(NB % 2 == 0, "accumulators are processed in pairs");
 };
 
 // workgroup barrier that waits for LDS traffic only (never for vmcnt)
@@ -131,6 +132,7 @@ template <int NB>
 __device__ __forceinline__ void loader_run(const float4* const* wseq, const float* const* bseq, int nseq, float4* lds,
                                            int lane) {
   using R = Ring<NB>;
+  __builtin_amdgcn_s_setprio(3);                   // the loader must never be the wave the others wait for
   constexpr int ROUND = 16;                        // float4 per lane per round (64 VGPRs)
   constexpr int PER = R::CH / 64;                  // float4 per lane per chunk
   int j = 0;
@@ -173,22 +175,29 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     const float4* cur = lds + ((j + c) & 1) * R::CH;
+    // fragment reads are written one (t, t+1) pair ahead of the 8 MFMAs that consume them; hipcc sinks them back
+    // next to their use (pinning the order with sched_barrier measured no gain: other waves hide the LDS latency)
+    constexpr int HP = NB / 2, NP = R::KB_PER * HP;      // pairs per chunk
+    float4 w0 = cur[lane], w1 = cur[64 + lane];
 #pragma unroll
-    for (int kk = 0; kk < R::KB_PER; ++kk) {
-      const int kb = c * R::KB_PER + kk;
-#pragma unroll
-      for (int t = 0; t < NB; t += 2) {
-        const float4 w0 = cur[(kk * NB + t) * 64 + lane];
-        const float4 w1 = cur[(kk * NB + (t + 1 < NB ? t + 1 : t)) * 64 + lane];
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, act[kb][0], acc[t], 0, 0, 0);
-        if (t + 1 < NB) acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, act[kb][0], acc[t + 1], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, act[kb][1], acc[t], 0, 0, 0);
-        if (t + 1 < NB) acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, act[kb][1], acc[t + 1], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, act[kb][2], acc[t], 0, 0, 0);
-        if (t + 1 < NB) acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, act[kb][2], acc[t + 1], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, act[kb][3], acc[t], 0, 0, 0);
-        if (t + 1 < NB) acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, act[kb][3], acc[t + 1], 0, 0, 0);
+    for (int pidx = 0; pidx < NP; ++pidx) {
+      const int kk = pidx / HP, t = 2 * (pidx % HP), kb = c * R::KB_PER + kk;
+      float4 n0 = w0, n1 = w1;
+      if (pidx + 1 < NP) {
+        const int kk2 = (pidx + 1) / HP, t2 = 2 * ((pidx + 1) % HP);
+        n0 = cur[(kk2 * NB + t2) * 64 + lane];
+        n1 = cur[(kk2 * NB + t2 + 1) * 64 + lane];
       }
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, act[kb][0], acc[t], 0, 0, 0);
+      acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, act[kb][0], acc[t + 1], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, act[kb][1], acc[t], 0, 0, 0);
+      acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, act[kb][1], acc[t + 1], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, act[kb][2], acc[t], 0, 0, 0);
+      acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, act[kb][2], acc[t + 1], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, act[kb][3], acc[t], 0, 0, 0);
+      acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, act[kb][3], acc[t + 1], 0, 0, 0);
+      w0 = n0;
+      w1 = n1;
     }
     lds_barrier();
   }
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  if (wave == 4) {  // loader wave (uniform branch)
+  if (wave == kComputeWaves) {  // loader wave (uniform branch)
     loader_run<NB>(a.wseq, a.bseq, a.nseq, lds, lane);
     return;
   }
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  if (wave == 4) {  // loader wave (uniform branch)
+  if (wave == kComputeWaves) {  // loader wave (uniform branch)
     loader_run<NB>(a.wseq, nullptr, a.nseq, lds, lane);
     return;
   }

@@ -1,0 +1,71 @@
+"""GPU: the HIP engine under data parallelism.  Two ranks (gloo, both on cuda:0 -- RCCL needs one GPU per rank,
+the 8-GPU run is the driver's) each take half of a batch; the all-reduced gradients and the exact global loss
+must equal one process running the whole batch, and a Trainer step must leave identical parameters on both ranks."""
+import os
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from conftest import Golden
+    from oracle import bsms_oracle as ro
+    import bsms_gnn_amd as eng
+
+    z, graphs = Golden("sim"), Golden("graphs")
+    es, ids = graphs.levels("del300")
+    cfg = ro.make_cfg(2, 32, 3, 3, 2)
+    B = 2                                               # golden batch of 2 -> one sample per rank
+    torch.manual_seed(50 + rank)                        # different init per rank: the broadcast must fix it
+    sim = eng.BSMS_Simulator(cfg)
+    if rank == 0:
+        sim.load_state_dict(z.state_dict())             # golden weights + warmed normalisers on rank 0 only
+    sim = sim.cuda()
+    c = lambda t: t.cuda()
+    sl = slice(rank, rank + 1)
+    data = (c(z.t("node_in")[sl]), c(z.t("tar")[sl]), c(z.t("mask")[sl]),
+            [c(e.unsqueeze(0)) for e in es], [c(i.unsqueeze(0)) for i in ids])
+    engine = eng.DataParallel(sim, bucket_bytes=64 << 10)
+    loss = engine.step_loss_backward(data, True)
+    flat = engine.grads.flat.clone()
+    # one fused optimizer step on the reduced gradients: parameters must stay identical across ranks
+    opt = eng.FusedAdamW(engine.grads, lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0)
+    opt.step()
+    torch.cuda.synchronize()
+    names = [k for k, p in sim.named_parameters() if p.requires_grad]
+    order = {p: k for k, p in sim.named_parameters()}
+    torch.save({"loss": loss.detach().cpu(), "flat": flat.cpu(), "params": opt.flat_p.cpu(),
+                "slot_names": [order[p] for p in reversed([q for q in sim.parameters() if q.requires_grad])],
+                "n_buckets": len(engine.grads.buckets), "names": names}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_single_process_large_batch(tmp_path):
+    from conftest import load_golden, rel_err
+    port = 29600 + os.getpid() % 2000
+    out = str(tmp_path / "res")
+    mp.start_processes(_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    z = load_golden("sim")
+    assert r0["n_buckets"] > 1
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["loss"], r1["loss"])     # bit-identical across ranks
+    assert torch.equal(r0["params"], r1["params"])                                         # ... also after the update
+    assert abs(float(r0["loss"]) - float(z.t("loss"))) < 1e-5 * abs(float(z.t("loss")))    # exact GLOBAL masked RMSE
+    # summed per-rank gradients == gradient of the single-process batch-2 step recorded in the golden file
+    want = torch.cat([z.t("g/" + k).reshape(-1) for k in r0["slot_names"]])
+    assert rel_err(r0["flat"], want) < 2e-5
