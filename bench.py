@@ -67,6 +67,30 @@ def build_workload(kind, batch, device, seed=0):
                 levels=[(n if l == 0 else len(m_ids[l - 1]), m_es[l].shape[1]) for l in range(len(m_es))], cfg=w)
 
 
+def build_blockdiag_workload(kind, batch, device):
+    """Variable-mesh layout (the reference's cylinder_flow path, consistent_mesh: false): `batch` DIFFERENT meshes
+    (Delaunay seeds 0..batch-1), collated into one block-diagonal graph per level (A15)."""
+    from scipy.spatial import Delaunay
+    import bsms_gnn_amd as eng
+    w = WORKLOADS[kind]
+    n, c = w["nodes"], w["out_dim"]
+    gen = torch.Generator().manual_seed(0)
+    samples = []
+    for seed in range(batch):
+        pts = np.random.default_rng(seed).random((n, 2))
+        flat = eng.to_flat_edge(Delaunay(pts).simplices.astype(np.int64), "tri")
+        _, m_es, m_ids = eng.BistrideMultiLayerGraph(flat, w["levels"], n, pts).get_multi_layer_graphs()
+        state, target = torch.randn(n, c, generator=gen), torch.randn(n, c, generator=gen)
+        x = torch.cat([state, torch.tensor(pts, dtype=torch.float32), torch.zeros(n, 1)], -1)
+        sizes = [n] + [len(i) for i in m_ids]
+        samples.append([eng.LevelData(torch.tensor(m_es[l]), sizes[l], face=torch.tensor(m_ids[l]) if l < w["levels"] else None,
+                                      x=x if l == 0 else None, y=target if l == 0 else None,
+                                      mask=torch.ones(n, 1) if l == 0 else None) for l in range(w["levels"] + 1)])
+    batchd = [d.to(device) for d in eng.collate_variable_meshes(samples)]
+    return dict(data=batchd, samples=samples, cfg=w,
+                levels=[(d.num_nodes, int(d.edge_index.shape[1])) for d in batchd])
+
+
 def make_cfg(w):
     from types import SimpleNamespace
     return SimpleNamespace(out_dim=w["out_dim"], latent_dim=w["latent"], hidden_layer=3, unet_depth=w["levels"],
@@ -196,6 +220,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="airfoil", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=8, help="batch per GPU")
+    ap.add_argument("--layout", default="dense", choices=["dense", "blockdiag"],
+                    help="dense: consistent mesh [B,N,.]; blockdiag: B different meshes as one block-diagonal graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the kernel micro-loops (for rocprofv3 --pmc passes)")
@@ -228,13 +254,18 @@ def main():
         return
     torch.manual_seed(0)
     sim = eng.BSMS_Simulator(make_cfg(wl["cfg"])).cuda()
-    data = data_tuple(wl)
-    sim(data, True, True)                                                 # one normaliser accumulation
+    consistent = args.layout == "dense"
+    if consistent:
+        data = data_tuple(wl)
+    else:
+        bd = build_blockdiag_workload(args.workload, args.batch, "cuda")
+        data, wl["levels"] = bd["data"], bd["levels"]
+    sim(data, consistent, True)                                           # one normaliser accumulation
     dp = eng.DataParallel(sim)
     dp.sync_normalizers()
 
     def step():
-        return dp.step_loss_backward(data, True)
+        return dp.step_loss_backward(data, consistent)
 
     for _ in range(args.warmup):
         step()
@@ -263,11 +294,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-like Delaunay mesh, {wl['cfg']['nodes']} nodes, "
                                    f"{wl['cfg']['levels']} bi-stride levels, D={wl['cfg']['latent']}, hidden_layer=3, "
-                                   f"batch {args.batch} per GPU (global {args.batch * world}), consistent mesh",
+                                   f"batch {args.batch} per GPU (global {args.batch * world}), "
+                                   + ("consistent mesh" if consistent else "block-diagonal batch of different meshes"),
                        "levels_N_E": wl["levels"], "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "trainable_params": n_params, "loss": float(loss.detach())},
         }
-        if world == 1 and not args.no_roofline:
+        if world == 1 and not args.no_roofline and consistent:
             line["roofline"], line["roofline_mfma"] = roofline_objects(wl, args.batch)
             line["rollout"] = rollout_rate(sim, wl)
         if world == 1 and not args.no_cpu_baseline:

@@ -408,3 +408,34 @@ def test_full_size_properties(eng):
         both = net(x, [i[0] for i in wl["m_ids"][:2]], [g[0] for g in wl["m_gs"][:3]], pos)
         one = net(x[1:], [i[0] for i in wl["m_ids"][:2]], [g[0] for g in wl["m_gs"][:3]], pos[1:])
     assert torch.equal(both[1:], one)
+
+
+def test_cylinder_blockdiag_equals_dense_at_full_size(eng):
+    """BASELINE configs[1] size (cylinder-like, 1885 nodes, 4 levels, D=128), B=3: the same mesh three times as a
+    block-diagonal batch (variable-mesh path) == the dense consistent-mesh batch, forward and loss."""
+    from bench import WORKLOADS, build_mesh, make_cfg
+    w = WORKLOADS["cylinder"]
+    pts, m_es, m_ids = build_mesh("cylinder")
+    n, c, B = w["nodes"], w["out_dim"], 3
+    torch.manual_seed(1)
+    sim = eng.BSMS_Simulator(make_cfg(w)).cuda()
+    state, target = torch.randn(B, n, c), torch.randn(B, n, c)
+    pos = torch.tensor(pts, dtype=torch.float32)
+    node_in = torch.cat([state, pos.expand(B, n, 2), torch.zeros(B, n, 1)], -1)
+    mask = torch.ones(B, n, 1)
+    dense = (node_in.cuda(), target.cuda(), mask.cuda(), [torch.tensor(e).unsqueeze(0).repeat(B, 1, 1).cuda() for e in m_es],
+             [torch.tensor(i).unsqueeze(0).repeat(B, 1).cuda() for i in m_ids])
+    sizes = [n] + [len(i) for i in m_ids]
+    samples = [[eng.LevelData(torch.tensor(m_es[l]), sizes[l], face=torch.tensor(m_ids[l]) if l < w["levels"] else None,
+                              x=node_in[b] if l == 0 else None, y=target[b] if l == 0 else None,
+                              mask=mask[b] if l == 0 else None) for l in range(w["levels"] + 1)] for b in range(B)]
+    blk = [d.to("cuda") for d in eng.collate_variable_meshes(samples)]
+    sim(dense, True, True)
+    with torch.no_grad():
+        p_dense = sim(dense, True, False)
+        p_blk = sim(blk, False, False)
+    assert p_blk.shape == (1, B * n, c)
+    assert rel_err(p_blk.view(B, n, c), p_dense) < 2e-6
+    l_dense = eng.masked_rmse(p_dense, dense[1], dense[2])
+    l_blk = eng.masked_rmse(p_blk, blk[0].y.unsqueeze(0), blk[0].mask.unsqueeze(0))
+    assert abs(float(l_dense) - float(l_blk)) < 1e-6 * float(l_dense)
