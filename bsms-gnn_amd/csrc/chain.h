@@ -1,22 +1,31 @@
-// MLP "chain" kernels for gfx950: the dense per-edge / per-node MLPs of the BSMS path on f32 MFMA.
+// MLP "chain" kernels for gfx950: the dense per-edge / per-node MLPs of the BSMS path on the matrix cores.
 //
-// Orientation.  Every Linear y = x W^T is computed TRANSPOSED, Y^T = W X^T, with
-// v_mfma_f32_16x16x4_f32 (exact f32): the A operand is a weight fragment (rows = output features), the B
-// operand an activation fragment (columns = rows of x, i.e. edges / nodes).  Each wave owns 16 rows of x:
-// lane l <-> row (l & 15), lane group g = l >> 4.  The 16x16 result block leaves a lane holding, for ITS row,
-// output features  f = 16 t + 4 g + r  (r = accumulator register 0..3, t = 16-feature block).
-// The MFMA sums over k in {0..3} supplied by the four lane groups; we are free to decide WHICH input feature
-// each (step s, group g) stands for, as long as A and B agree.  Choosing
-//          k(s, g) = 16 kb + 4 g + s
-// makes the accumulator layout of one layer exactly the B-operand layout of the next: activations never
-// leave registers between layers -- no LDS round trip, no HBM traffic.  LayerNorm over a row is 32 in-lane
-// values + two cross-group exchanges.  16-row tiles keep a D=128 kernel near 100-160 VGPRs (3-4 waves/SIMD).
+// Orientation.  Every Linear y = x W^T is computed TRANSPOSED, Y^T = W X^T: the A operand of an MFMA is a weight
+// fragment (rows = output features), the B operand an activation fragment (columns = rows of x, i.e. edges /
+// nodes).  Each wave owns 16 rows of x: lane l <-> row (l & 15), lane group g = l >> 4.  The 16x16 result block
+// leaves a lane holding, for ITS row, output features  f = 16 t + 4 g + r  (r = accumulator register 0..3,
+// t = 16-feature block).  An MFMA sums over K slots (g, i) supplied by the four lane groups; we are free to decide
+// WHICH input feature each slot stands for, as long as A and B agree.  Choosing, for the 32-feature K block kb2,
+//          feature(g, i) = 16 (2 kb2 + (i >> 2)) + 4 g + (i & 3),      i = 0..7
+// makes the accumulator layout of one layer exactly the B-operand layout of the next: activations never leave
+// registers between layers -- no LDS round trip, no HBM traffic.  LayerNorm over a row is 32 in-lane values + two
+// cross-group exchanges.
 //
-// Weights are re-laid out once per call ("prepack") into fragment order
-//          Wp[kb][t][lane] = float4{ W[16 t + (lane & 15)][16 kb + 4 (lane >> 4) + 0..3] }
-// (a float4 of the original row-major nn.Linear weight), so a K-chunk (32 input features x all outputs; 16 KB
-// at D = 128) is contiguous: the workgroup streams chunks L2 -> LDS through a 2-deep ring (one barrier per
-// chunk) and every wave reads its A fragments with conflict-free, lane-linear ds_read_b128.
+// Arithmetic: fp32 results from v_mfma_f32_16x16x32_bf16 by EXACT three-way splitting.  An fp32 value is the sum
+// of three bf16 numbers, x = hi + mid + lo (8 + 8 + 8 significand bits, by truncation: the split is exact), for
+// both operands; a product x*w is accumulated in fp32 as the six partial products whose weight is >= 2^-16,
+//          hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid);
+// the three dropped terms are <= 2^-24 |x w| each, the size of an fp32 rounding.  Measured against an fp64 product
+// the result is no worse than the f32 MFMA it replaces (rms 6e-8 vs 1.4e-7), at 16/6 = 2.7x its throughput
+// (v_mfma_f32_16x16x4_f32: 64 flop/cycle/SIMD, the bf16 form 1024).  Inputs, outputs, accumulation, LayerNorm and
+// everything stored to HBM stay fp32.
+//
+// Weights are re-laid out once per call ("prepack") into chunks, one per 32-feature K block:
+//          [1 KB header: the Linear's bias (chunk 0 of a pack) or zeros]
+//          [t][plane hi|mid|lo][lane] 16 bytes = the 8 bf16 of A-fragment (t, kb2) for that lane
+// (25 KB per chunk at D = 128).  A LOADER wave streams chunks L2 -> LDS with LDS-DMA (global_load_lds_dwordx4, no
+// registers, two chunks in flight) through a 3-deep ring, one workgroup barrier per chunk; compute waves read
+// their A fragments with conflict-free lane-linear ds_read_b128.
 #pragma once
 #include "common.h"
 
@@ -26,6 +35,9 @@ constexpr int kMaxStages = 8;   // max Linear layers per MLP handled by one chai
 constexpr int kComputeWaves = 4;                       // compute waves per workgroup (each owns 16 rows)
 constexpr int kTileRows = kComputeWaves * 16;          // rows of x per workgroup
 constexpr int kChainThreads = (kComputeWaves + 1) * 64;  // + 1 loader wave
+constexpr int kChunkHdrFloats = 256;                     // 1 KB chunk header (bias)
+// floats in one weight pack of a D x D Linear (bf16 x 3 planes + headers)
+constexpr size_t pack_floats(int64_t D) { return size_t(D / 32) * (kChunkHdrFloats + size_t(D / 16) * 768); }
 
 enum ChainIn { IN_ROWS = 0, IN_ROWS2 = 1, IN_SMALL = 2, IN_EDGE = 3 };
 enum ChainOut { OUT_LN = 0, OUT_PLAIN = 1, OUT_SMALL = 2 };
@@ -34,6 +46,7 @@ enum GradFirst { F_NONE = 0, F_HEADS1 = 1, F_HEADS2 = 2 };
 
 struct ChainFwdArgs {
   int64_t R;  // rows
+  int ntiles; // filled by the launcher: ceil(R / kTileRows); workgroups stride over tiles (persistent)
   // ---- input stage
   const float* x;    // IN_ROWS/IN_ROWS2: [R,D]; IN_SMALL: [R,K0]
   const float* x2;   // IN_ROWS2: second source [R,D]
@@ -49,9 +62,8 @@ struct ChainFwdArgs {
   int p;
   // ---- MFMA stages
   int nstage;
-  const float4* wp[kMaxStages];
+  const float4* wp[kMaxStages];  // packs (the Linear's bias travels in the pack header, see PackDesc)
   const float4* wp0b;  // IN_ROWS2: pack for x2 in stage 0
-  const float* bias[kMaxStages];
   float* store[kMaxStages];  // post-ReLU activation of stage l (nullable)
   // ---- output
   float* y;           // OUT_LN / OUT_PLAIN: [R,D]; OUT_SMALL: [R,C]
@@ -62,16 +74,17 @@ struct ChainFwdArgs {
   const float* wout;  // OUT_SMALL: [C][D]
   const float* bout;  // OUT_SMALL: [C]
   int C;
+  unsigned long long* timing;  // experiments only: per-workgroup s_memtime stamps (16 slots), null in production
   int store_mode;     // saved-activation stores: 0 plain, 1 non-temporal (keeps L2 for weights / gathered rows)
   int out_mode;       // same for the final output y
-  // ---- filled by launch_chain_fwd: weight packs / biases in execution order for the loader wave
+  // ---- filled by launch_chain_fwd: weight packs in execution order for the loader wave
   int nseq;
   const float4* wseq[kMaxStages + 2];
-  const float* bseq[kMaxStages + 2];
 };
 
 struct ChainBwdArgs {
   int64_t R;
+  int ntiles;         // filled by the launcher (persistent workgroups stride over tiles)
   const float* dy;    // G_ROWS_LN: [R,D]; G_EDGE_LN: [B*N,D] node gradient gathered by dst; G_SMALL: [R,C]
   const float* yln;   // LN cases: normalised forward output [R,D]
   const float* rstd;  // LN cases: [R]
@@ -98,10 +111,11 @@ struct ChainBwdArgs {
 enum PackKind { PACK_FRAG = 0, PACK_FRAG_T = 1, PACK_TRANSPOSE = 2 };
 struct PackDesc {
   const float* W;  // row-major, leading dimension ld
-  float* dst;
+  const float* bias;  // FRAG kinds: [N] copied into the header of chunk 0 (nullable -> zeros)
+  float* dst;      // FRAG kinds: pack_floats(N) floats
   int ld, row0, col0;
   int N, K;  // logical matrix M[n][k], n < N (outputs), k < K (reduction)
-  int kind;  // FRAG: M[n][k] = W[row0+n][col0+k]; FRAG_T: M[n][k] = W[row0+k][col0+n];
+  int kind;  // FRAG: M[n][k] = W[row0+n][col0+k]; FRAG_T: M[n][k] = W[row0+k][col0+n];   (N == K, multiple of 32)
              // TRANSPOSE: dst[k*N+n] = W[row0+n][col0+k] (plain, for the small VALU layers)
 };
 constexpr int kMaxPack = 40;

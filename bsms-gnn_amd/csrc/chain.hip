@@ -11,26 +11,51 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // For every 16-feature block t the lane holds features 16 t + 4 g + {0,1,2,3} as one f32x4.
 
 // ---------------------------------------------------------------------------------- prepack ----
-// FRAG  : dst[((kb*NB + t)*64 + lane)*4 + s] = M[16 t + (lane & 15)][16 kb + 4 (lane >> 4) + s]
-// with M[n][k] = W[row0+n][col0+k] (FRAG) or W[row0+k][col0+n] (FRAG_T); NB = N/16, kb < K/16.
+// exact three-way bf16 split by truncation: x = hi + mid + lo, each piece's low 16 bits are zero
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  lo = __float_as_uint(r1 - __uint_as_float(mid));  // <= 8 significant bits left: already a bf16
+}
+
+// FRAG packs (layout in chain.h): per 32-feature K block c a chunk of kChunkHdrFloats + NB*768 dwords;
+//   body dword ((t*3 + plane)*64 + lane)*4 + v  =  bf16 pair (slots 2v, 2v+1) of plane `plane` of
+//   M[16 t + (lane & 15)][16 (2c + (i >> 2)) + 4 (lane >> 4) + (i & 3)],  i = slot
+// with M[n][k] = W[row0+n][col0+k] (FRAG) or W[row0+k][col0+n] (FRAG_T).
 __global__ __launch_bounds__(256) void k_prepack(PackTable tab) {
   const PackDesc d = tab.d[blockIdx.y];
-  const int total = d.N * d.K;
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
-    int n, k;
-    if (d.kind == PACK_TRANSPOSE) {
-      k = o / d.N;
-      n = o % d.N;
-    } else {
-      const int sidx = o & 3, lane = (o >> 2) & 63;
-      const int rest = o >> 8, nb = d.N >> 4;
-      const int t = rest % nb, kb = rest / nb;
-      n = 16 * t + (lane & 15);
-      k = 16 * kb + 4 * (lane >> 4) + sidx;
+  if (d.kind == PACK_TRANSPOSE) {
+    const int total = d.N * d.K;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+      const int k = o / d.N, n = o % d.N;
+      d.dst[o] = d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
     }
-    const float v = (d.kind == PACK_FRAG_T) ? d.W[int64_t(d.row0 + k) * d.ld + d.col0 + n]
-                                            : d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
-    d.dst[o] = v;
+    return;
+  }
+  const int nb = d.N >> 4, chf = kChunkHdrFloats + nb * 768;
+  const int total = (d.K >> 5) * chf;
+  unsigned* dst = reinterpret_cast<unsigned*>(d.dst);
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+    const int c = o / chf, w = o % chf;
+    if (w < kChunkHdrFloats) {
+      d.dst[o] = (c == 0 && d.bias && w < d.N) ? d.bias[w] : 0.f;
+      continue;
+    }
+    const int q = w - kChunkHdrFloats;
+    const int v = q & 3, lane = (q >> 2) & 63, tp = q >> 8, plane = tp % 3, t = tp / 3;
+    unsigned piece[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = 2 * v + e;
+      const int n = 16 * t + (lane & 15), k = 16 * (2 * c + (i >> 2)) + 4 * (lane >> 4) + (i & 3);
+      const float x = (d.kind == PACK_FRAG_T) ? d.W[int64_t(d.row0 + k) * d.ld + d.col0 + n]
+                                              : d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
+      unsigned hi, mid, lo;
+      split3(x, hi, mid, lo);
+      piece[e] = plane == 0 ? hi : plane == 1 ? mid : lo;
+    }
+    dst[o] = (piece[0] >> 16) | (piece[1] & 0xffff0000u);
   }
 }
 
@@ -92,16 +117,11 @@ __device__ __forceinline__ float row_sum(const f32x4 (&v)[NB]) {
   return group_sum(s);
 }
 
-// One Linear: acc[t] += sum_kb W(kb,t) * act[kb] on v_mfma_f32_16x16x4_f32.  The A operand of step s is the
-// weight fragment W[16t + (l&15)][16kb + 4g + s], the B operand this lane's own act[kb][s].  Weight chunks
-// (32 input features x all outputs) stream L2 -> registers -> LDS ring; one __syncthreads per chunk.
-// Two accumulators are interleaved so back-to-back MFMAs are independent (40-cycle dependent latency vs
-// 32-cycle issue).  All waves of the workgroup must call this together.
 // ---------------------------------------------------------------------------- weight streaming
-// Workgroup = 4 compute waves + 1 LOADER wave.  The loader streams the weight packs of all stages of the
-// kernel, chunk by chunk (a chunk = 32 input features x all outputs, 16 KB at D = 128), from L2 into a 2-deep
-// LDS ring, always one chunk ahead of the compute waves and straight across stage boundaries; with a stage's
-// first chunk it also drops the stage's bias into LDS.  One workgroup barrier per chunk.
+// Workgroup = 4 compute waves + 1 LOADER wave.  The loader streams the weight packs of all stages of every tile of
+// this workgroup, chunk by chunk (a chunk = 32 input features x all outputs x 3 bf16 planes + header, 25 KB at
+// D = 128), from L2 into a 3-deep LDS ring with LDS-DMA: no registers, two chunks in flight, a counted
+// s_waitcnt vmcnt before it publishes a chunk at the workgroup barrier.  One barrier per chunk.
 //
 // Why a separate wave: vmcnt retires loads and stores through one in-order counter and hipcc waits vmcnt(0)
 // whenever both kinds are outstanding, so a compute wave that fetched its own weights would stop at every chunk
@@ -110,112 +130,124 @@ __device__ __forceinline__ float row_sum(const f32x4 (&v)[NB]) {
 // steady state; their stores drain in the background.
 template <int NB>
 struct Ring {
-  static constexpr int KB_PER = NB >= 2 ? 2 : 1;  // 16-feature k blocks per chunk
-  static constexpr int NCH = NB / KB_PER;         // chunks per stage
-  static constexpr int CH = KB_PER * NB * 64;     // float4 per chunk
   static constexpr int D = NB * 16;
-  static constexpr size_t lds_bytes = size_t(2) * CH * sizeof(float4) + size_t(2) * D * sizeof(float);
-  static_assert(CH % 64 == 0, "chunk must be a whole number of float4 per loader lane");
-  static_assert(NB % 2 == 0, "accumulators are processed in pairs");
+  static constexpr int NCH = NB / 2;                          // chunks per stage (one per 32-feature K block)
+  static constexpr int CHF = kChunkHdrFloats + NB * 768;      // floats per chunk
+  static constexpr int CH4 = CHF / 4;                         // float4 per chunk
+  static constexpr int PER = CHF / 256;                       // LDS-DMA instructions (1 KB each) per chunk
+  static constexpr int NR = 3;                                // ring depth
+  static constexpr size_t lds_bytes = size_t(NR) * CHF * sizeof(float);
+  static_assert(CHF % 256 == 0 && PER < 64, "chunk = whole LDS-DMA instructions, countable by vmcnt");
+  static_assert(NB % 2 == 0, "K blocks are pairs of 16-feature blocks");
 };
 
-// workgroup barrier that waits for LDS traffic only (never for vmcnt)
+// workgroup barrier that waits for this wave's LDS traffic only (never for vmcnt)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NB>
-__device__ __forceinline__ float* ring_bias(float4* lds, int stage) {
-  return reinterpret_cast<float*>(lds + 2 * Ring<NB>::CH) + (stage & 1) * Ring<NB>::D;
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_dst, +1 KB) in lane order.  Invisible to
+// hipcc's waitcnt bookkeeping (inline asm), which is the point: the loader counts its own vmcnt.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 // the loader wave's whole life
 template <int NB>
-__device__ __forceinline__ void loader_run(const float4* const* wseq, const float* const* bseq, int nseq, float4* lds,
-                                           int lane) {
+__device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles) {
   using R = Ring<NB>;
   __builtin_amdgcn_s_setprio(3);                   // the loader must never be the wave the others wait for
-  constexpr int ROUND = 16;                        // float4 per lane per round (64 VGPRs)
-  constexpr int PER = R::CH / 64;                  // float4 per lane per chunk
-  int j = 0;
-  for (int s = 0; s < nseq; ++s) {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wseq[s]);
-    for (int c = 0; c < R::NCH; ++c, ++j) {
-      f32x4* dst = reinterpret_cast<f32x4*>(lds) + (j & 1) * R::CH;
-      const f32x4* src = wp + c * R::CH;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+  const int my_tiles = (ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+  const int per_tile = nseq * R::NCH, total = my_tiles * per_tile;
+  int is = 0, ic = 0, islot = 0;                   // next chunk to issue: sequence entry, chunk in it, ring slot
+  auto issue = [&]() {
+    const float4* src = wseq[is] + size_t(ic) * R::CH4 + lane;
+    const unsigned dst = lds0 + unsigned(islot) * unsigned(R::CHF * sizeof(float));
 #pragma unroll
-      for (int r0 = 0; r0 < PER; r0 += ROUND) {
-        f32x4 v[ROUND];
-#pragma unroll
-        for (int i = 0; i < ROUND; ++i)
-          if (r0 + i < PER) v[i] = src[(r0 + i) * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < ROUND; ++i)
-          if (r0 + i < PER) dst[(r0 + i) * 64 + lane] = v[i];
-      }
-      if (c == 0 && bseq && bseq[s]) {
-        float* bl = ring_bias<NB>(lds, s);
-        for (int f = lane; f < R::D; f += 64) bl[f] = bseq[s][f];
-      }
-      lds_barrier();                               // publishes chunk j (compute waves arrive after chunk j-1)
-    }
+    for (int i = 0; i < R::PER; ++i) glds16(src + i * 64, dst + i * 1024);
+    if (++ic == R::NCH) { ic = 0; if (++is == nseq) is = 0; }
+    if (++islot == R::NR) islot = 0;
+  };
+  if (total > 0) issue();
+  if (total > 1) issue();
+  for (int j = 0; j < total; ++j) {
+    // chunk j has landed once at most the (whole) younger chunk is still outstanding
+    if (j + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R::PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");       // barrier #j: publishes chunk j; everyone is done with chunk j-1,
+    if (j + 2 < total) issue();                    // whose slot chunk j+2 now overwrites
   }
-  lds_barrier();                                   // pairs with the compute waves' barrier after the last chunk
 }
 
-// One Linear on the compute waves: acc[t] += sum_kb W(kb,t) * act[kb] with v_mfma_f32_16x16x4_f32.  The A operand
-// of step s is the weight fragment W[16t + (l&15)][16kb + 4g + s] (lane-linear ds_read_b128 from the ring), the B
-// operand this lane's own act[kb][s].  `j` = running chunk counter (ring slot = j & 1).  Two accumulators are
-// interleaved so back-to-back MFMAs are independent (40-cycle dependent latency vs 32-cycle issue).
-// `store_row` (nullable): this lane's row of an HBM tensor that receives `act`; issued with the first chunk so the
-// store has the whole stage to drain.
+// bf16 pieces of one lane's activations as B operands: plane[kb2] = 8 bf16 = slots i of K block kb2 (chain.h)
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
 template <int NB>
-__device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& j, int lane,
-                                           float* store_row = nullptr, int store_mode = 0) {
+__device__ __forceinline__ void split_tile(const f32x4 (&act)[NB], u32x4 (&bh)[NB / 2], u32x4 (&bm)[NB / 2],
+                                           u32x4 (&bl)[NB / 2]) {
+#pragma unroll
+  for (int kb2 = 0; kb2 < NB / 2; ++kb2)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {  // dword v = slots 2v, 2v+1 = act[2 kb2 + (v >> 1)][2 (v & 1) + {0, 1}]
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3(act[2 * kb2 + (v >> 1)][2 * (v & 1)], h0, m0, l0);
+      split3(act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1], h1, m1, l1);
+      bh[kb2][v] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+      bm[kb2][v] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+      bl[kb2][v] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// One Linear on the compute waves: acc[t] (+)= sum_k W[16t + ., k] * act[k] with the six bf16 partial products.
+// `slot` = ring slot of the stage's first chunk (advanced here).  `from_header`: start acc from the bias in the
+// header of the stage's first chunk instead of accumulating onto the caller's acc.
+// `store_row` (nullable): this lane's row of an HBM tensor that receives `act`; issued right after the split so
+// the store has the whole stage to drain.  All compute waves of the workgroup must call this together.
+template <int NB>
+__device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
+                                           bool from_header, float* store_row = nullptr, int store_mode = 0) {
   using R = Ring<NB>;
+  u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
+  split_tile<NB>(act, bh, bm, bl);
   store_rows<NB, false>(act, store_row, lane >> 4, store_mode);
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
-    const float4* cur = lds + ((j + c) & 1) * R::CH;
-    // fragment reads are written one (t, t+1) pair ahead of the 8 MFMAs that consume them; hipcc sinks them back
-    // next to their use (pinning the order with sched_barrier measured no gain: other waves hide the LDS latency)
-    constexpr int HP = NB / 2, NP = R::KB_PER * HP;      // pairs per chunk
-    float4 w0 = cur[lane], w1 = cur[64 + lane];
+    lds_barrier();                                           // chunk has landed (and my reads of the last one are done)
+    const float4* cur = lds + slot * R::CH4;
+    if (++slot == R::NR) slot = 0;
+    if (c == 0 && from_header) {
+      const float* bl_ = reinterpret_cast<const float*>(cur);
 #pragma unroll
-    for (int pidx = 0; pidx < NP; ++pidx) {
-      const int kk = pidx / HP, t = 2 * (pidx % HP), kb = c * R::KB_PER + kk;
-      float4 n0 = w0, n1 = w1;
-      if (pidx + 1 < NP) {
-        const int kk2 = (pidx + 1) / HP, t2 = 2 * ((pidx + 1) % HP);
-        n0 = cur[(kk2 * NB + t2) * 64 + lane];
-        n1 = cur[(kk2 * NB + t2 + 1) * 64 + lane];
+      for (int t = 0; t < NB; ++t) {
+        const float4 x = *reinterpret_cast<const float4*>(bl_ + 16 * t + 4 * (lane >> 4));
+        acc[t] = f32x4{x.x, x.y, x.z, x.w};
       }
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, act[kb][0], acc[t], 0, 0, 0);
-      acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, act[kb][0], acc[t + 1], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, act[kb][1], acc[t], 0, 0, 0);
-      acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, act[kb][1], acc[t + 1], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, act[kb][2], acc[t], 0, 0, 0);
-      acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, act[kb][2], acc[t + 1], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, act[kb][3], acc[t], 0, 0, 0);
-      acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, act[kb][3], acc[t + 1], 0, 0, 0);
-      w0 = n0;
-      w1 = n1;
     }
-    lds_barrier();
-  }
-  j += R::NCH;
-}
-
-// acc = bias of sequence entry `stage` (from the ring) or 0
-template <int NB>
-__device__ __forceinline__ void init_acc(f32x4 (&acc)[NB], float4* lds, int stage, bool has_bias, int lg) {
-  if (has_bias) {
-    const float* bl = ring_bias<NB>(lds, stage);
+    const float4* body = cur + kChunkHdrFloats / 4 + lane;
+    // two accumulators interleaved so that back-to-back MFMAs are independent; smallest terms first
 #pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      const float4 x = *reinterpret_cast<const float4*>(bl + 16 * t + 4 * lg);
-      acc[t] = f32x4{x.x, x.y, x.z, x.w};
+    for (int t = 0; t < NB; t += 2) {
+      const float4 h0 = body[(t * 3 + 0) * 64], m0 = body[(t * 3 + 1) * 64], l0 = body[(t * 3 + 2) * 64];
+      const float4 h1 = body[(t * 3 + 3) * 64], m1 = body[(t * 3 + 4) * 64], l1 = body[(t * 3 + 5) * 64];
+      acc[t] = mma(l0, bh[c], acc[t]);
+      acc[t + 1] = mma(l1, bh[c], acc[t + 1]);
+      acc[t] = mma(h0, bl[c], acc[t]);
+      acc[t + 1] = mma(h1, bl[c], acc[t + 1]);
+      acc[t] = mma(m0, bm[c], acc[t]);
+      acc[t + 1] = mma(m1, bm[c], acc[t + 1]);
+      acc[t] = mma(m0, bh[c], acc[t]);
+      acc[t + 1] = mma(m1, bh[c], acc[t + 1]);
+      acc[t] = mma(h0, bm[c], acc[t]);
+      acc[t + 1] = mma(h1, bm[c], acc[t + 1]);
+      acc[t] = mma(h0, bh[c], acc[t]);
+      acc[t + 1] = mma(h1, bh[c], acc[t + 1]);
     }
-  } else {
-    zero_tile<NB>(acc);
   }
 }
 
@@ -256,16 +288,31 @@ __device__ __forceinline__ float dot_features(const f32x4 (&v)[NB], const float*
 
 // -------------------------------------------------------------------------------- forward chain
 template <int NB, int IN, int OUT>
-__global__ __launch_bounds__(kChainThreads) void k_chain_fwd(ChainFwdArgs a) {
+__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   if (wave == kComputeWaves) {  // loader wave (uniform branch)
-    loader_run<NB>(a.wseq, a.bseq, a.nseq, lds, lane);
+    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles);
     return;
   }
-  const int64_t row = int64_t(blockIdx.x) * kTileRows + wave * 16 + (lane & 15);
+  int slot = 0;  // ring slot of the next chunk; runs on across this workgroup's tiles exactly like the loader's
+  // Persistent workgroups: the grid is sized to what the chip holds at once and strides over the tiles, so a CU
+  // never waits for the dispatcher to refill a slot (measured: 20-35 % of slot time was empty with one
+  // workgroup per tile) and the loader is already fetching the next tile's first chunk during this epilogue.
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  const int64_t row = int64_t(tile) * kTileRows + wave * 16 + (lane & 15);
   const bool live = row < a.R;
+  int stamp_i = 0;
+  auto stamp = [&]() {  // experiments: wave 0 / lane 0 records the shader clock at phase boundaries
+    if (a.timing && tid == 0 && stamp_i < 16) a.timing[int64_t(tile) * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
+  if (a.timing && tid == 0) {
+    a.timing[int64_t(tile) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+    a.timing[int64_t(tile) * 16 + 13] = (uint64_t(__builtin_amdgcn_s_getreg(63508)) << 32) |  // XCC_ID
+                                        uint32_t(__builtin_amdgcn_s_getreg(63492));             // HW_ID
+  }
 
   f32x4 act[NB], acc[NB];
 
@@ -303,19 +350,17 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_fwd(ChainFwdArgs a) {
   }
 
   // ---- MFMA stages.  The activation entering a stage is stored to HBM from inside that stage (mfma_stage).
-  int j = 0, sq = 0;  // ring chunk counter, index into the loader's weight sequence
-  lds_barrier();      // chunk 0 (+ bias of the first stage) is in the ring
+  stamp();            // input stage done
+  stamp();
   float* pending = ((IN == IN_SMALL || IN == IN_EDGE) && live && a.store_in) ? a.store_in + row * D : nullptr;
   if (a.nstage == 0 && pending) store_rows<NB, false>(act, pending, lg);
   for (int l = 0; l < a.nstage; ++l) {
-    init_acc<NB>(acc, lds, sq, a.bias[l] != nullptr, lg);
-    mfma_stage<NB>(acc, act, lds, j, lane, pending, a.store_mode);
-    ++sq;
+    mfma_stage<NB>(acc, act, lds, slot, lane, true, pending, a.store_mode);  // acc = bias + W act
+    stamp();          // stage l done
     pending = nullptr;
     if (IN == IN_ROWS2 && l == 0) {
       load_rows<NB>(act, live ? a.x2 + row * D : nullptr, lg);
-      mfma_stage<NB>(acc, act, lds, j, lane);
-      ++sq;
+      mfma_stage<NB>(acc, act, lds, slot, lane, false);
     }
     const bool last = (l == a.nstage - 1);
     if (!last || OUT == OUT_SMALL) {
@@ -324,7 +369,9 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_fwd(ChainFwdArgs a) {
       else if (live && a.store[l]) store_rows<NB, false>(act, a.store[l] + row * D, lg);
     }
   }
-  if (!live) return;
+  stamp();
+  if (a.timing && tid == 0) a.timing[int64_t(tile) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+  if (!live) continue;
 
   // ---- output
   if (OUT == OUT_LN) {  // LayerNorm(elementwise_affine=False), eps 1e-5  (ops/basic.py:18)
@@ -351,6 +398,10 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_fwd(ChainFwdArgs a) {
       for (int t = 0; t < NB; ++t) acc[t] += act[t];
     }
     store_rows<NB, false>(acc, a.y + row * D, lg, a.out_mode);
+    if (a.timing && tid == 0) {
+      __builtin_amdgcn_s_waitcnt(0);  // experiments: all of this wave's stores acknowledged
+      a.timing[int64_t(tile) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+    }
   } else if (OUT == OUT_PLAIN) {
     if (a.accumulate) store_rows<NB, true>(acc, a.y + row * D, lg);
     else store_rows<NB, false>(acc, a.y + row * D, lg);
@@ -360,6 +411,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_fwd(ChainFwdArgs a) {
       if (lg == 0) a.y[row * a.C + c] = v + a.bout[c];
     }
   }
+  }  // tile loop
 }
 
 // ------------------------------------------------------------------------------- backward chain
@@ -376,15 +428,17 @@ __device__ __forceinline__ void mask_by(f32x4 (&gr)[NB], const float* act_row, i
 }
 
 template <int NB, int GIN, int FIRST>
-__global__ __launch_bounds__(kChainThreads) void k_chain_bwd(ChainBwdArgs a) {
+__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   if (wave == kComputeWaves) {  // loader wave (uniform branch)
-    loader_run<NB>(a.wseq, nullptr, a.nseq, lds, lane);
+    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles);
     return;
   }
-  const int64_t row = int64_t(blockIdx.x) * kTileRows + wave * 16 + (lane & 15);
+  int slot = 0;  // ring slot of the next chunk, across this workgroup's tiles
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {  // persistent workgroups (see k_chain_fwd)
+  const int64_t row = int64_t(tile) * kTileRows + wave * 16 + (lane & 15);
   const bool live = row < a.R;
 
   f32x4 g[NB], acc[NB];
@@ -420,13 +474,11 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_bwd(ChainBwdArgs a) {
   }
   // The gradient entering a stage is stored to HBM from inside that stage (mfma_stage), so the store has a whole
   // stage to drain before the next vmcnt wait (the ReLU-mask rows at the end of the stage).
-  int j = 0;
-  lds_barrier();      // chunk 0 is in the ring
   float* pending = (live && a.gstore[0]) ? a.gstore[0] + row * D : nullptr;
 
   for (int k = 0; k < a.nstage; ++k) {
     zero_tile<NB>(acc);
-    mfma_stage<NB>(acc, g, lds, j, lane, pending, a.store_mode);
+    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, a.store_mode);
     const bool masked = live && a.mask[k];
     if (masked) load_rows<NB>(g, a.mask[k] + row * D, lg);            // g is consumed: reuse it for the mask rows
 #pragma unroll
@@ -438,7 +490,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_bwd(ChainBwdArgs a) {
 
   if (FIRST != F_NONE) {
     zero_tile<NB>(acc);
-    mfma_stage<NB>(acc, g, lds, j, lane, pending);
+    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending);
     pending = nullptr;
     if (live && a.dres) {
       f32x4 r[NB];
@@ -449,7 +501,7 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_bwd(ChainBwdArgs a) {
     if (FIRST == F_HEADS2) {
       f32x4 acc2[NB];
       zero_tile<NB>(acc2);
-      mfma_stage<NB>(acc2, g, lds, j, lane);
+      mfma_stage<NB>(acc2, g, lds, slot, lane, false);
       if (live) {
         store_rows<NB, false>(acc, a.dx + row * D, lg);
         store_rows<NB, false>(acc2, a.dx2 + row * D, lg);
@@ -459,6 +511,25 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_bwd(ChainBwdArgs a) {
     }
   }
   if (pending) store_rows<NB, false>(g, pending, lg);
+  }  // tile loop
+}
+
+// Workgroups of 5 waves the chip keeps resident per CU at each width.  NOT the occupancy API's answer: the SPI
+// accounts a 5-wave workgroup like an 8-wave one (census: 320 threads x 120 VGPRs -> 2 per CU where the API says 3;
+// profiles/census).  A grid larger than the residency would only queue, a smaller one idles slots.
+template <int NB>
+constexpr int resident_per_cu() { return NB <= 4 ? 4 : NB == 8 ? 2 : 1; }
+
+template <int NB>
+unsigned persistent_grid(int64_t ntiles) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return (unsigned)std::min<int64_t>(ntiles, int64_t(cus) * resident_per_cu<NB>());
 }
 
 template <int NB, int IN, int OUT>
@@ -466,11 +537,15 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   ChainFwdArgs a = a0;
   a.nseq = 0;
   for (int l = 0; l < a.nstage; ++l) {  // the loader follows exactly the compute waves' stage order
-    a.wseq[a.nseq] = a.wp[l]; a.bseq[a.nseq++] = a.bias[l];
-    if (IN == IN_ROWS2 && l == 0) { a.wseq[a.nseq] = a.wp0b; a.bseq[a.nseq++] = nullptr; }
+    a.wseq[a.nseq++] = a.wp[l];
+    if (IN == IN_ROWS2 && l == 0) a.wseq[a.nseq++] = a.wp0b;
   }
   const size_t lds = Ring<NB>::lds_bytes;
-  hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3((unsigned)ceil_div(a.R, kTileRows)), dim3(kChainThreads), lds, s, a);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve %zu bytes of LDS", lds);
+  a.ntiles = (int)ceil_div(a.R, kTileRows);
+  hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -498,7 +573,11 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   if (FIRST != F_NONE) a.wseq[a.nseq++] = a.wh0;
   if (FIRST == F_HEADS2) a.wseq[a.nseq++] = a.wh1;
   const size_t lds = Ring<NB>::lds_bytes;
-  hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3((unsigned)ceil_div(a.R, kTileRows)), dim3(kChainThreads), lds, s, a);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", lds);
+  a.ntiles = (int)ceil_div(a.R, kTileRows);
+  hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -516,6 +595,15 @@ int launch_bwd_n(int gin, int first, const ChainBwdArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// experiments only (not in bsms_hip.h): what residency does the runtime compute for the D = 128 edge chains?
+extern "C" int bsms_debug_occupancy(int* fwd_blocks_per_cu, int* bwd_blocks_per_cu) {
+  hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(fwd_blocks_per_cu, k_chain_fwd<8, IN_EDGE, OUT_LN>,
+                                                                kChainThreads, Ring<8>::lds_bytes);
+  hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(bwd_blocks_per_cu, k_chain_bwd<8, G_EDGE_LN, F_NONE>,
+                                                                kChainThreads, Ring<8>::lds_bytes);
+  return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -4;
+}
 
 namespace bsms {
 

@@ -38,11 +38,13 @@ struct Carver {  // identical walk for size queries (base == nullptr) and real b
 bool supported_D(int64_t D) { return D == 32 || D == 64 || D == 128 || D == 256; }
 
 static int env_flags() { const char* e = getenv("BSMS_DEBUG_FLAGS"); return e ? atoi(e) : 0; }
+unsigned long long* g_timing = nullptr;
 int g_debug_flags = env_flags();  // experiments only: bit0 skip fwd activation stores, bit1 plain (not nt) stores, bit2 nt final y
 
-void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, int K, int kind, float* dst) {
+void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, int K, int kind, float* dst,
+              const float* bias = nullptr) {
   PackDesc& d = t.d[t.n++];
-  d.W = W; d.dst = dst; d.ld = ld; d.row0 = row0; d.col0 = col0; d.N = N; d.K = K; d.kind = kind;
+  d.W = W; d.bias = bias; d.dst = dst; d.ld = ld; d.row0 = row0; d.col0 = col0; d.N = N; d.K = K; d.kind = kind;
 }
 
 // ================================================================================== GMP layout
@@ -59,7 +61,7 @@ struct GmpSaved {
 GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H, bool training = true) {
   Carver c(base);
   GmpSaved s{};
-  const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = size_t(D) * D;
+  const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
   if (training)
     for (int l = 0; l < H; ++l) s.e_act[l] = c.take(re * D);
   s.e_y = c.take(re * D);
@@ -117,6 +119,7 @@ int check_gmp(const bsms_plan_t* plan, int64_t B, int64_t D, int64_t p, int H, c
 
 // =================================================================================== GMP entries
 extern "C" void bsms_debug_set_flags(int flags) { g_debug_flags = flags; }  // not in bsms_hip.h: experiments only
+extern "C" void bsms_debug_set_timing(unsigned long long* dev_buf) { g_timing = dev_buf; }
 
 extern "C" size_t bsms_gmp_saved_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden) {
   if (hidden < 1 || hidden >= kMaxStages) return 0;
@@ -145,7 +148,7 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
                          : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false);  // lives in the gradient scratch
 
   PackTable t{};
-  add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG, sv.e_wi);
+  add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG, sv.e_wi, pe[1]);
   add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG, sv.e_wj);
   add_pack(t, pe[0], ldE0, 0, 0, (int)D, int(p + 1), PACK_TRANSPOSE, sv.e_wft);
   if (training) {
@@ -153,17 +156,17 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
     add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG_T, sv.e_wjt);
   }
   for (int l = 1; l <= H; ++l) {
-    add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.e_w[l]);
+    add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.e_w[l], pe[2 * l + 1]);
     if (training) add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]);
   }
-  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x);
+  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x, pn[1]);
   add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG, sv.n_w0a);
   if (training) {
     add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_w0xt);
     add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG_T, sv.n_w0at);
   }
   for (int l = 1; l <= H; ++l) {
-    add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w[l]);
+    add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w[l], pn[2 * l + 1]);
     if (training) add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_wt[l]);
   }
   if ((rc = launch_prepack(t, s))) return rc;
@@ -172,9 +175,9 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
   {
     ChainFwdArgs a{};
     a.R = B * N; a.x = x; a.nstage = 1;
-    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wi); a.bias[0] = pe[1]; a.y = wk.Ps;
+    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wi); a.y = wk.Ps;   // bias b0 rides in the pack header
     if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN, a, s))) return rc;
-    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wj); a.bias[0] = nullptr; a.y = wk.Pd;
+    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wj); a.y = wk.Pd;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN, a, s))) return rc;
   }
   // edge MLP + LayerNorm
@@ -186,10 +189,10 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
     a.nstage = H;
     for (int st = 0; st < H; ++st) {
       a.wp[st] = reinterpret_cast<const float4*>(sv.e_w[st + 1]);
-      a.bias[st] = pe[2 * (st + 1) + 1];
       a.store[st] = (training && st < H - 1) ? sv.e_act[st + 1] : nullptr;
     }
     a.y = sv.e_y; a.rstd = sv.e_rstd;
+    a.timing = g_timing;
     a.store_mode = (g_debug_flags & 2) ? 0 : 1;   // saved activations are streamed with non-temporal stores
     a.out_mode = (g_debug_flags & 4) ? 1 : 0;
     if (g_debug_flags & 1) {
@@ -206,10 +209,9 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
     a.R = B * N; a.x = x; a.x2 = sv.aggr; a.nstage = H + 1;
     a.wp[0] = reinterpret_cast<const float4*>(sv.n_w0x);
     a.wp0b = reinterpret_cast<const float4*>(sv.n_w0a);
-    a.bias[0] = pn[1]; a.store[0] = training ? sv.n_act[0] : nullptr;
+    a.store[0] = training ? sv.n_act[0] : nullptr;
     for (int st = 1; st <= H; ++st) {
       a.wp[st] = reinterpret_cast<const float4*>(sv.n_w[st]);
-      a.bias[st] = pn[2 * st + 1];
       a.store[st] = (training && st < H) ? sv.n_act[st] : nullptr;
     }
     a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x;
@@ -352,7 +354,7 @@ MlpSaved carve_mlp_saved(void* base, int64_t R, int64_t D, int H, bool training 
     s.yln = c.take(size_t(R) * D);
     s.rstd = c.take(size_t(R));
   }
-  for (int l = 0; l <= H; ++l) { s.w[l] = c.take(size_t(D) * D); if (training) s.wt[l] = c.take(size_t(D) * D); }
+  for (int l = 0; l <= H; ++l) { s.w[l] = c.take(pack_floats(D)); if (training) s.wt[l] = c.take(pack_floats(D)); }
   s.w0t = c.take(size_t(16) * D);
   s.bytes = c.off;
   return s;
@@ -411,7 +413,7 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
   const int llast = (kind == MLP_ROWS_SMALL) ? H - 1 : H;     // last one
   if (kind == MLP_SMALL_LN) add_pack(t, params[0], (int)in_dim, 0, 0, (int)D, (int)in_dim, PACK_TRANSPOSE, sv.w0t);
   for (int l = lfirst; l <= llast; ++l) {
-    add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.w[l]);
+    add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.w[l], params[2 * l + 1]);
     if (training) add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.wt[l]);
   }
   if ((rc = launch_prepack(t, s))) return rc;
@@ -424,7 +426,6 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
   }
   for (int l = lfirst; l <= llast; ++l, ++st) {
     a.wp[st] = reinterpret_cast<const float4*>(sv.w[l]);
-    a.bias[st] = params[2 * l + 1];
     a.store[st] = (training && l < H) ? sv.act[l] : nullptr;
   }
   a.nstage = st;
