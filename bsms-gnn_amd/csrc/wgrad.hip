@@ -1,21 +1,28 @@
 // Weight-gradient kernels: dW = G^T A with the reduction over (up to millions of) edge / node rows.
 //
-// k_wgrad: split-K f32-MFMA GEMM.  A workgroup owns one 128x128 block of dW and a contiguous slab of
-// rows; 32-row chunks of G and A stream HBM -> registers -> LDS (2-deep ring, row-major exactly as
-// they sit in HBM, so the loads are full 512-byte bursts) and feed v_mfma_f32_32x32x2_f32 with
-// conflict-free ds_read_b32 (lanes run along the feature axis for both operands).  Partial blocks go
-// to a workspace and are summed in slab order by k_reduce (deterministic; no float atomics).  Several
-// layers' gradients are batched into one launch so the small coarse levels still fill the chip.
-// The bias gradient (column sums of G) rides along for free from the LDS tile.
+// k_wgrad: split-K GEMM on v_mfma_f32_16x16x32_bf16 with the same exact three-way bf16 split as the chain kernels
+// (chain.h): both operands are fp32 in HBM, split ONCE per element while they are staged into LDS, and every
+// product is accumulated in fp32 as six bf16 partial products.  The reduction index (rows) is the MFMA's K, so an
+// operand fragment is 8 consecutive ROWS of one column: a lane stages exactly that -- one column of G and one of A
+// for 8 rows (4-byte loads, 16 lanes = one 64-byte row segment), splits its 16 values and writes three 16-byte
+// fragments per matrix, already in MFMA order ([plane][column][row group], a wave's reads and writes are
+// contiguous 1 KB: conflict-free).  A workgroup owns one 128x128 block of dW and a contiguous slab of rows, 32 rows
+// per chunk, next chunk's loads in flight during the MFMAs; 48 KB of LDS -> two workgroups per CU alternate
+// staging and MFMA phases.  At this rate the kernel is HBM bound (two fp32 streams, each read once).
+// Partial blocks go to a workspace and are summed in slab order by k_wgrad_reduce (deterministic; no float
+// atomics).  Several layers' gradients are batched into one launch so the small coarse levels still fill the
+// chip.  The bias gradient (column sums of G) is accumulated in fp32 by the staging lanes.
 #include "chain.h"
 
 using namespace bsms;
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int TB = 128;  // dW block edge
-constexpr int RC = 32;   // rows per chunk
+constexpr int RC = 32;   // rows per chunk (= K of one MFMA)
 
 struct WgradTable {
   int njobs, D, nblk;
@@ -27,9 +34,35 @@ struct WgradTable {
   float* colsums;    // [tiles][TB]
 };
 
-__global__ __launch_bounds__(512) void k_wgrad(WgradTable tab) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][G|A][RC][TB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {  // exact: x = hi + mid + lo
+  hi = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  lo = __float_as_uint(r1 - __uint_as_float(mid));
+}
+
+// 8 fp32 (consecutive rows of one column) -> three fragments of 8 bf16
+__device__ __forceinline__ void split_column(const float (&v)[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(v[2 * q], h0, m0, l0);
+    split3(v[2 * q + 1], h1, m1, l1);
+    h[q] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    m[q] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    l[q] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
+  }
+}
+
+__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_wgrad(WgradTable tab) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 frag[];  // [G|A][plane][column 0..127][row group 0..3]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
   int j = 0;
   while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
   const WgradJob job = tab.job[j];
@@ -41,75 +74,88 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradTable tab) {
   const int nchunk = int((r1 - r0 + RC - 1) / RC);
   const int n0 = bi * TB, k0 = bj * TB;
 
-  // staging: 512 threads move one 32-row chunk of G and of A (2 x 16 KB): 2 float4 of each per thread
-  // (row = tid/32 + 16 i, col4 = tid%32) -- full 512-byte row bursts
-  const int srow = tid >> 5, scol = (tid & 31) * 4;
-  float4 sg[2], sa[2];
+  // staging: this lane owns column 16 wave + m of the G block and of the A block, rows 8 g .. 8 g + 7 of a chunk
+  const int col = 16 * wave + m;
+  const bool vg = n0 + col < D, va = k0 + col < D;
+  const float* gcol = job.G + n0 + col;
+  const float* acol = job.A + k0 + col;
+  float gv[8], av[8];
   auto fetch = [&](int chunk) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t r = r0 + int64_t(chunk) * RC + srow + 16 * i;
+    for (int i = 0; i < 8; ++i) {
+      const int64_t r = r0 + int64_t(chunk) * RC + 8 * g + i;
       const bool rv = r < r1;
-      sg[i] = (rv && n0 + scol < D) ? *reinterpret_cast<const float4*>(job.G + r * job.ldg + n0 + scol)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-      sa[i] = (rv && k0 + scol < D) ? *reinterpret_cast<const float4*>(job.A + r * job.lda + k0 + scol)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      gv[i] = (rv && vg) ? gcol[r * job.ldg] : 0.f;
+      av[i] = (rv && va) ? acol[r * job.lda] : 0.f;
     }
   };
-  auto stash = [&](int buf) {
-    float* g = lds + buf * (2 * RC * TB);
-    float* a = g + RC * TB;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4*>(g + (srow + 16 * i) * TB + scol) = sg[i];
-      *reinterpret_cast<float4*>(a + (srow + 16 * i) * TB + scol) = sa[i];
-    }
+  const bool want_db = job.db && bj == 0;
+  float csum = 0.f;  // partial column sum of G over this lane's rows
+  auto stash = [&]() {
+    u32x4 h, mm, l;
+    split_column(gv, h, mm, l);
+    frag[(0 * TB + col) * 4 + g] = h;
+    frag[(1 * TB + col) * 4 + g] = mm;
+    frag[(2 * TB + col) * 4 + g] = l;
+    if (want_db) csum += ((gv[0] + gv[1]) + (gv[2] + gv[3])) + ((gv[4] + gv[5]) + (gv[6] + gv[7]));
+    split_column(av, h, mm, l);
+    frag[(3 * TB + col) * 4 + g] = h;
+    frag[(4 * TB + col) * 4 + g] = mm;
+    frag[(5 * TB + col) * 4 + g] = l;
   };
 
-  // 8 waves: wave owns dW rows [32 wr, +32) x cols [64 wc, +64)  (LDS allows 2 workgroups per CU, so 8 waves per
-  // workgroup = 4 waves per SIMD to cover the LDS-read and barrier latencies)
+  // 8 waves: wave owns dW rows [32 wr, +32) x cols [64 wc, +64) = 2 x 4 MFMA blocks
   const int wr = wave >> 1, wc = wave & 1;
-  f32x16 acc[2];
+  f32x4 acc[2][4];
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
-  float csum = 0.f;  // thread tid < TB sums column tid of the G tile
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nchunk > 0) {
-    fetch(0);
-    stash(0);
-  }
-  __syncthreads();
+  if (nchunk > 0) fetch(0);
   for (int c = 0; c < nchunk; ++c) {
-    const float* g = lds + (c & 1) * (2 * RC * TB);
-    const float* a = g + RC * TB;
-    if (c + 1 < nchunk) fetch(c + 1);
+    stash();                          // split + store this chunk's fragments (waits for its loads)
+    if (c + 1 < nchunk) fetch(c + 1);  // next chunk's rows fly during the MFMAs
+    wg_barrier();
+    u32x4 gh[2], gm[2], gl[2];
 #pragma unroll
-    for (int s = 0; s < RC / 2; ++s) {
-      const int rr = 2 * s + hh;
-      const float a0 = g[rr * TB + 32 * wr + l31];
-      const float b0 = a[rr * TB + 64 * wc + l31], b1 = a[rr * TB + 64 * wc + 32 + l31];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+    for (int a = 0; a < 2; ++a) {
+      const int o = (32 * wr + 16 * a + m) * 4 + g;
+      gh[a] = frag[0 * TB * 4 + o]; gm[a] = frag[1 * TB * 4 + o]; gl[a] = frag[2 * TB * 4 + o];
     }
-    if (job.db && bj == 0 && tid < TB) {
-#pragma unroll 8
-      for (int rr = 0; rr < RC; ++rr) csum += g[rr * TB + tid];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int o = (64 * wc + 16 * b + m) * 4 + g;
+      const u32x4 ah = frag[3 * TB * 4 + o], am = frag[4 * TB * 4 + o], al = frag[5 * TB * 4 + o];
+      acc[0][b] = mma(gl[0], ah, acc[0][b]);
+      acc[1][b] = mma(gl[1], ah, acc[1][b]);
+      acc[0][b] = mma(gh[0], al, acc[0][b]);
+      acc[1][b] = mma(gh[1], al, acc[1][b]);
+      acc[0][b] = mma(gm[0], am, acc[0][b]);
+      acc[1][b] = mma(gm[1], am, acc[1][b]);
+      acc[0][b] = mma(gm[0], ah, acc[0][b]);
+      acc[1][b] = mma(gm[1], ah, acc[1][b]);
+      acc[0][b] = mma(gh[0], am, acc[0][b]);
+      acc[1][b] = mma(gh[1], am, acc[1][b]);
+      acc[0][b] = mma(gh[0], ah, acc[0][b]);
+      acc[1][b] = mma(gh[1], ah, acc[1][b]);
     }
-    if (c + 1 < nchunk) stash((c + 1) & 1);
-    __syncthreads();
+    wg_barrier();                     // everyone is done reading before the next stash overwrites
   }
 
+  // D[row = 4 g + r][col = m] of block (a, b) = dW[32 wr + 16 a + 4 g + r][64 wc + 16 b + m]
   float* part = tab.partials + int64_t(blockIdx.x) * (TB * TB);
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      part[n * TB + 64 * wc + 32 * jj + l31] = acc[jj][r];
-    }
-  if (job.db && bj == 0 && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = csum;
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(32 * wr + 16 * a + 4 * g + r) * TB + 64 * wc + 16 * b + m] = acc[a][b][r];
+  if (want_db) {
+    csum += __shfl_xor(csum, 16, 64);
+    csum += __shfl_xor(csum, 32, 64);
+    if (g == 0) tab.colsums[int64_t(blockIdx.x) * TB + col] = csum;
+  }
 }
 
 // dW[n][col0+k] = sum over slabs of the partial blocks; db likewise.  A block owns 64 float4 outputs; its 4
@@ -317,7 +363,7 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   tab.first_tile[njobs] = first;
   tab.partials = reinterpret_cast<float*>(work);
   tab.colsums = tab.partials + size_t(kMaxTiles) * TB * TB;
-  const size_t lds = size_t(2) * 2 * RC * TB * sizeof(float);
+  const size_t lds = size_t(6) * TB * 4 * sizeof(u32x4);   // 48 KB: [G|A][3 planes][128 columns][4 row groups] x 16 B
   hipLaunchKernelGGL(k_wgrad, dim3(first), dim3(512), lds, s, tab);
   BSMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div((D * D + D) / 4, 64), njobs), dim3(256), 0, s, tab);
