@@ -2,27 +2,36 @@
 //
 // k_wgrad: split-K GEMM on v_mfma_f32_16x16x32_bf16 with the same exact three-way bf16 split as the chain kernels
 // (chain.h): both operands are fp32 in HBM, split ONCE per element while they are staged into LDS, and every
-// product is accumulated in fp32 as six bf16 partial products.  The reduction index (rows) is the MFMA's K, so an
-// operand fragment is 8 consecutive ROWS of one column: a lane stages exactly that -- one column of G and one of A
-// for 8 rows (4-byte loads, 16 lanes = one 64-byte row segment), splits its 16 values and writes three 16-byte
-// fragments per matrix, already in MFMA order ([plane][column][row group], a wave's reads and writes are
-// contiguous 1 KB: conflict-free).  A workgroup owns one 128x128 block of dW and a contiguous slab of rows, 32 rows
-// per chunk, next chunk's loads in flight during the MFMAs; 48 KB of LDS -> two workgroups per CU alternate
-// staging and MFMA phases.  At this rate the kernel is HBM bound (two fp32 streams, each read once).
-// Partial blocks go to a workspace and are summed in slab order by k_wgrad_reduce (deterministic; no float
-// atomics).  Several layers' gradients are batched into one launch so the small coarse levels still fill the
-// chip.  The bias gradient (column sums of G) is accumulated in fp32 by the staging lanes.
+// product is accumulated in fp32 as six bf16 partial products.  A workgroup owns one 128x128 block of dW and a
+// contiguous slab of rows, 32 rows per chunk:
+//   stage   1024 threads load the chunk of G and of A row-major (16-byte loads, full 512-byte row bursts, three
+//           chunks ahead in registers), split every value into its hi/mid/lo bf16 and store three row-major bf16 planes per
+//           matrix (row pitch 288 B so that 8 consecutive rows hit disjoint banks);
+//   MFMA    the reduction index (rows) is the MFMA's K, i.e. an operand fragment is a COLUMN of 8 rows per lane:
+//           ds_read_b64_tr_b16 delivers exactly that from the row-major planes (a 16-lane group transposes a
+//           4-row x 16-column block), two reads per fragment, no bank conflicts.
+// The planes are double buffered (108 KB, one 16-wave workgroup per CU, one barrier per chunk): a wave stages chunk
+// c+1, then multiplies chunk c, and the four waves of a SIMD overlap each other's phases.  At this rate the kernel is HBM bound
+// (two fp32 streams, each read once).  Partial blocks go to a workspace and are summed in slab order by
+// k_wgrad_reduce (deterministic; no float atomics).  Several layers' gradients are batched into one launch so the
+// small coarse levels still fill the chip.  The bias gradient (column sums of G) is accumulated in fp32 by the
+// staging threads.
 #include "chain.h"
+#include <type_traits>
 
 using namespace bsms;
 
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-constexpr int TB = 128;  // dW block edge
-constexpr int RC = 32;   // rows per chunk (= K of one MFMA)
+constexpr int TB = 128;    // dW block edge
+constexpr int RC = 32;     // rows per chunk (= K of one MFMA)
+constexpr int LROW = 144;  // bf16 per LDS row: 128 columns + 16 pad (288 B: 8 banks further per row)
+constexpr int PLANE = RC * LROW;
 
 struct WgradTable {
   int njobs, D, nblk;
@@ -32,6 +41,7 @@ struct WgradTable {
   WgradJob job[kMaxWgradJobs];
   float* partials;   // [tiles][TB*TB]
   float* colsums;    // [tiles][TB]
+  unsigned long long* timing;  // experiments only: per-workgroup s_memtime stamps (null in production)
 };
 
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {  // exact: x = hi + mid + lo
@@ -41,28 +51,48 @@ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, uns
   lo = __float_as_uint(r1 - __uint_as_float(mid));
 }
 
-// 8 fp32 (consecutive rows of one column) -> three fragments of 8 bf16
-__device__ __forceinline__ void split_column(const float (&v)[8], u32x4& h, u32x4& m, u32x4& l) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split3(v[2 * q], h0, m0, l0);
-    split3(v[2 * q + 1], h1, m1, l1);
-    h[q] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-    m[q] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-    l[q] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
-  }
+// 4 fp32 (consecutive columns of one row) -> 4 bf16 per plane
+__device__ __forceinline__ void split_quad(const f32x4& v, u32x2& h, u32x2& m, u32x2& l) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  split3(v[0], h0, m0, l0);
+  split3(v[1], h1, m1, l1);
+  h[0] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+  m[0] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+  l[0] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
+  split3(v[2], h0, m0, l0);
+  split3(v[3], h1, m1, l1);
+  h[1] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+  m[1] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+  l[1] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
 }
 
-__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+// MFMA operand of one 16-column block from a row-major plane: lane (c = lane & 15, q = lane >> 4) receives column
+// `col0 + c`, rows 4q..4q+3 (slots 0-3) and 16+4q..16+4q+3 (slots 4-7).  ds_read_b64_tr_b16: within a 16-lane group
+// lane i' supplies the 8 bytes at its address and lane i receives element (i & 3) of suppliers 4k + (i >> 2), k = 0..3
+// (profiles/census/tr_test.hip), so supplier i' points at row (i' >> 2), columns 4 (i' & 3)...
+__device__ __forceinline__ bf16x8 column_fragment(const short* plane, int col0, int lane) {
+  const int q = lane >> 4, ip = lane & 15;
+  const short* p = plane + (4 * q + (ip >> 2)) * LROW + col0 + 4 * (ip & 3);
+  using lds_s16x4 = __attribute__((address_space(3))) s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * LROW));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_wgrad(WgradTable tab) {
-  extern __shared__ __attribute__((aligned(16))) u32x4 frag[];  // [G|A][plane][column 0..127][row group 0..3]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+constexpr int WG_THREADS = 1024;  // 16 waves = 4 per SIMD, one workgroup per CU
+constexpr int NPF = 3;            // chunks in flight in registers beyond the one being staged
+static_assert(NPF == 3, "the step schedule in k_wgrad is written out for three register sets");
+
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
+  extern __shared__ __attribute__((aligned(16))) short planes[];  // [2 buffers][G|A][hi|mid|lo][32 rows][LROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int j = 0;
   while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
   const WgradJob job = tab.job[j];
@@ -74,59 +104,87 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   const int nchunk = int((r1 - r0 + RC - 1) / RC);
   const int n0 = bi * TB, k0 = bj * TB;
 
-  // staging: this lane owns column 16 wave + m of the G block and of the A block, rows 8 g .. 8 g + 7 of a chunk
-  const int col = 16 * wave + m;
-  const bool vg = n0 + col < D, va = k0 + col < D;
-  const float* gcol = job.G + n0 + col;
-  const float* acol = job.A + k0 + col;
-  float gv[8], av[8];
-  auto fetch = [&](int chunk) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int64_t r = r0 + int64_t(chunk) * RC + 8 * g + i;
-      const bool rv = r < r1;
-      gv[i] = (rv && vg) ? gcol[r * job.ldg] : 0.f;
-      av[i] = (rv && va) ? acol[r * job.lda] : 0.f;
-    }
+  // staging: 1024 threads move one 32-row chunk of G and of A, one float4 of each per thread (row = tid / 32,
+  // columns 4 (tid % 32) ..): full 512-byte row bursts, NPF chunks ahead in registers
+  const int srow = tid >> 5, scol = (tid & 31) * 4;
+  const bool vg = n0 + scol < D, va = k0 + scol < D;
+  // loads are unconditional (a predicated load costs a branch and a vmcnt(0)): out-of-range rows / columns read a
+  // valid address and are zeroed when they are staged
+  const float* gsrc = job.G + (vg ? n0 + scol : 0);
+  const float* asrc = job.A + (va ? k0 + scol : 0);
+  const int64_t rlast = r1 - 1;
+  f32x4 sg[NPF], sa[NPF];
+  bool live[NPF];
+  auto fetch = [&](int chunk, int set) {   // chunks past the slab re-read its last rows (never staged)
+    const int64_t r = r0 + int64_t(chunk) * RC + srow;
+    live[set] = r < r1;
+    const int64_t rc = r < r1 ? r : rlast;
+    sg[set] = *reinterpret_cast<const f32x4*>(gsrc + rc * job.ldg);
+    sa[set] = *reinterpret_cast<const f32x4*>(asrc + rc * job.lda);
   };
   const bool want_db = job.db && bj == 0;
-  float csum = 0.f;  // partial column sum of G over this lane's rows
-  auto stash = [&]() {
-    u32x4 h, mm, l;
-    split_column(gv, h, mm, l);
-    frag[(0 * TB + col) * 4 + g] = h;
-    frag[(1 * TB + col) * 4 + g] = mm;
-    frag[(2 * TB + col) * 4 + g] = l;
-    if (want_db) csum += ((gv[0] + gv[1]) + (gv[2] + gv[3])) + ((gv[4] + gv[5]) + (gv[6] + gv[7]));
-    split_column(av, h, mm, l);
-    frag[(3 * TB + col) * 4 + g] = h;
-    frag[(4 * TB + col) * 4 + g] = mm;
-    frag[(5 * TB + col) * 4 + g] = l;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};  // column sums of G over this thread's rows
+  auto stash = [&](int set, int buf) {
+    short* dst = planes + buf * (6 * PLANE) + srow * LROW + scol;
+    u32x2 h, m, l;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 gq = (live[set] && vg) ? sg[set] : zero, aq = (live[set] && va) ? sa[set] : zero;
+    split_quad(gq, h, m, l);
+    *reinterpret_cast<u32x2*>(dst + 0 * PLANE) = h;
+    *reinterpret_cast<u32x2*>(dst + 1 * PLANE) = m;
+    *reinterpret_cast<u32x2*>(dst + 2 * PLANE) = l;
+    if (want_db) csum += gq;
+    split_quad(aq, h, m, l);
+    *reinterpret_cast<u32x2*>(dst + 3 * PLANE) = h;
+    *reinterpret_cast<u32x2*>(dst + 4 * PLANE) = m;
+    *reinterpret_cast<u32x2*>(dst + 5 * PLANE) = l;
   };
 
-  // 8 waves: wave owns dW rows [32 wr, +32) x cols [64 wc, +64) = 2 x 4 MFMA blocks
-  const int wr = wave >> 1, wc = wave & 1;
-  f32x4 acc[2][4];
+  // 16 waves: wave owns dW rows [32 wr, +32) x cols [32 wc, +32) = 2 x 2 MFMA blocks
+  const int wr = wave >> 2, wc = wave & 3;
+  f32x4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nchunk > 0) fetch(0);
-  for (int c = 0; c < nchunk; ++c) {
-    stash();                          // split + store this chunk's fragments (waits for its loads)
-    if (c + 1 < nchunk) fetch(c + 1);  // next chunk's rows fly during the MFMAs
-    wg_barrier();
-    u32x4 gh[2], gm[2], gl[2];
+  // chunk c is staged from register set c % NPF into LDS buffer c & 1 one iteration before its MFMAs; one barrier
+  // per chunk orders "buffer written" and "buffer free" at once
+  if (nchunk == 0) {   // cannot happen for a launched slab; keeps the unconditional loads in range
+    float* part0 = tab.partials + int64_t(blockIdx.x) * (TB * TB);
+    for (int o = tid; o < TB * TB; o += WG_THREADS) part0[o] = 0.f;
+    if (want_db && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = 0.f;
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < NPF; ++c) fetch(c, c);
+  stash(0, 0);
+  fetch(NPF, 0);
+  wg_barrier();
+  // one chunk: stage chunk c + 1 (register set SET1 -> buffer BUF ^ 1), refill that set, multiply chunk c from BUF.
+  // (Running the two halves in opposite order on every other wave of a SIMD, so that its VALU and matrix pipes
+  // overlap, measured no gain: profiles/wgrad_timeline.py shows a step of ~4.1k cycles = issue-bound, 25-30 % of it
+  // barrier skew.)
+  auto stage_next = [&](int c, auto set1_tag, auto buf_tag) {
+    constexpr int SET1 = decltype(set1_tag)::value, BUF = decltype(buf_tag)::value;
+    stash(SET1, BUF ^ 1);          // past the last chunk this stages zeros nobody reads
+    fetch(c + 1 + NPF, SET1);
+  };
+  auto multiply = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const short* buf = planes + BUF * (6 * PLANE);
+    bf16x8 gh[2], gm[2], gl[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const int o = (32 * wr + 16 * a + m) * 4 + g;
-      gh[a] = frag[0 * TB * 4 + o]; gm[a] = frag[1 * TB * 4 + o]; gl[a] = frag[2 * TB * 4 + o];
+      gh[a] = column_fragment(buf + 0 * PLANE, 32 * wr + 16 * a, lane);
+      gm[a] = column_fragment(buf + 1 * PLANE, 32 * wr + 16 * a, lane);
+      gl[a] = column_fragment(buf + 2 * PLANE, 32 * wr + 16 * a, lane);
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int o = (64 * wc + 16 * b + m) * 4 + g;
-      const u32x4 ah = frag[3 * TB * 4 + o], am = frag[4 * TB * 4 + o], al = frag[5 * TB * 4 + o];
+    for (int b = 0; b < 2; ++b) {
+      const bf16x8 ah = column_fragment(buf + 3 * PLANE, 32 * wc + 16 * b, lane);
+      const bf16x8 am = column_fragment(buf + 4 * PLANE, 32 * wc + 16 * b, lane);
+      const bf16x8 al = column_fragment(buf + 5 * PLANE, 32 * wc + 16 * b, lane);
       acc[0][b] = mma(gl[0], ah, acc[0][b]);
       acc[1][b] = mma(gl[1], ah, acc[1][b]);
       acc[0][b] = mma(gh[0], al, acc[0][b]);
@@ -140,21 +198,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       acc[0][b] = mma(gh[0], ah, acc[0][b]);
       acc[1][b] = mma(gh[1], ah, acc[1][b]);
     }
-    wg_barrier();                     // everyone is done reading before the next stash overwrites
+  };
+  int stamp_i = 0;
+  auto stamp = [&]() {  // experiments: waves 0 and 4 record the shader clock (64 slots each)
+    if (tab.timing && (tid == 0 || tid == 256) && stamp_i < 64)
+      tab.timing[(int64_t(blockIdx.x) * 2 + (tid >> 8)) * 64 + stamp_i++] = __builtin_amdgcn_s_memtime();
+  };
+  auto step = [&](int c, auto set1_tag, auto buf_tag) {
+    stamp();
+    stage_next(c, set1_tag, buf_tag);
+    stamp();
+    multiply(buf_tag);
+    stamp();
+    wg_barrier();
+  };
+  using std::integral_constant;
+  // 6 = lcm(register sets, buffers): both are compile-time in every step.  The body has no conditional step (a
+  // skipped step would make hipcc's vmcnt bookkeeping pessimistic: vmcnt(0) instead of leaving two chunks in
+  // flight); chunks past the slab are zeros and add nothing -- the launcher makes slabs multiples of 6 chunks.
+  for (int c = 0; c < nchunk; c += 6) {
+    step(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    step(c + 1, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    step(c + 2, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    step(c + 3, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    step(c + 4, integral_constant<int, 2>{}, integral_constant<int, 0>{});
+    step(c + 5, integral_constant<int, 0>{}, integral_constant<int, 1>{});
   }
 
-  // D[row = 4 g + r][col = m] of block (a, b) = dW[32 wr + 16 a + 4 g + r][64 wc + 16 b + m]
+  // D[row = 4 q + r][col = c] of block (a, b) = dW[32 wr + 16 a + 4 q + r][32 wc + 16 b + c]
+  const int q = lane >> 4, cc = lane & 15;
   float* part = tab.partials + int64_t(blockIdx.x) * (TB * TB);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part[(32 * wr + 16 * a + 4 * g + r) * TB + 64 * wc + 16 * b + m] = acc[a][b][r];
-  if (want_db) {
-    csum += __shfl_xor(csum, 16, 64);
-    csum += __shfl_xor(csum, 32, 64);
-    if (g == 0) tab.colsums[int64_t(blockIdx.x) * TB + col] = csum;
+      for (int r = 0; r < 4; ++r) part[(32 * wr + 16 * a + 4 * q + r) * TB + 32 * wc + 16 * b + cc] = acc[a][b][r];
+  if (want_db) {  // combine the 32 row-threads of each column quad in fixed order through LDS
+    f32x4* red = reinterpret_cast<f32x4*>(planes);
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < 32) {
+      f32x4 v = red[tid];
+      for (int l = 1; l < 32; ++l) v += red[l * 32 + tid];
+      *reinterpret_cast<f32x4*>(tab.colsums + int64_t(blockIdx.x) * TB + tid * 4) = v;
+    }
   }
 }
 
@@ -324,6 +412,9 @@ __global__ __launch_bounds__(256) void k_colsum_small(const float* S, int64_t R,
 
 }  // namespace
 
+static unsigned long long* g_wgrad_timing = nullptr;
+extern "C" void bsms_debug_set_wgrad_timing(unsigned long long* dev_buf) { g_wgrad_timing = dev_buf; }  // experiments only
+
 namespace bsms {
 
 size_t wgrad_work_bytes(int D, int njobs) {
@@ -343,9 +434,9 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   const int blocks = tab.nblk * tab.nblk;
   int64_t total_rows = 0;
   for (int j = 0; j < njobs; ++j) total_rows += jobs[j].R;
-  // aim for ~768 workgroups over all jobs; slabs are multiples of RC rows, at least 128
-  int64_t rows_per = std::max<int64_t>(128, ceil_div(total_rows * blocks, 768));
-  rows_per = ceil_div(rows_per, RC) * RC;
+  // aim for ~512 workgroups (two per CU, one resident at a time) over all jobs; slabs are multiples of RC rows, at least 128
+  int64_t rows_per = std::max<int64_t>(128, ceil_div(total_rows * blocks, 512));
+  rows_per = ceil_div(rows_per, 6 * RC) * (6 * RC);   // whole groups of six chunks (k_wgrad's step schedule)
   for (;;) {
     int64_t tiles = 0;
     for (int j = 0; j < njobs; ++j) tiles += std::max<int64_t>(1, ceil_div(jobs[j].R, rows_per)) * blocks;
@@ -363,8 +454,12 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   tab.first_tile[njobs] = first;
   tab.partials = reinterpret_cast<float*>(work);
   tab.colsums = tab.partials + size_t(kMaxTiles) * TB * TB;
-  const size_t lds = size_t(6) * TB * 4 * sizeof(u32x4);   // 48 KB: [G|A][3 planes][128 columns][4 row groups] x 16 B
-  hipLaunchKernelGGL(k_wgrad, dim3(first), dim3(512), lds, s, tab);
+  tab.timing = g_wgrad_timing;
+  const size_t lds = size_t(2) * 6 * PLANE * sizeof(short);   // 108 KB: 2 x [G|A][3 planes][32 rows][288 B]
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS", lds);
+  hipLaunchKernelGGL(k_wgrad, dim3(first), dim3(WG_THREADS), lds, s, tab);
   BSMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div((D * D + D) / 4, 64), njobs), dim3(256), 0, s, tab);
   BSMS_LAUNCH_CHECK();
