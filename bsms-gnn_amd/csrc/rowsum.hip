@@ -43,8 +43,42 @@ __device__ __forceinline__ float4 accum(float4 acc, float4 v, float w) {
 }
 
 // LPR lanes cooperate on one output row; each lane owns float4 column groups c4, c4+LPR, ...
-template <int LPR, bool WEIGHTED, bool MAPPED>
-__global__ __launch_bounds__(256) void k_rowsum_v4(RowSumArgs a) {
+// One batch of U consecutive CSR slots, branch-free: all index loads, then all row loads, then the sums strictly in
+// slot order.  (With the optional-pointer tests and the "skip" branch inside the unrolled loop hipcc serialises the
+// batch -- an s_waitcnt vmcnt(0) before every row load -- and the coarse levels, which have too few waves to hide
+// that, run at a fifth of the bandwidth.)  A skipped slot (MAPPED, negative map entry) reads row 0 and is dropped
+// by a select, so the accumulator sees exactly the sequence of additions scatter_add_ performs.
+template <int U, bool WEIGHTED, bool MAPPED, bool HAS_XIDX, bool HAS_WIDX>
+__device__ __forceinline__ float4 rowsum_batch(const RowSumArgs& a, const float* xcol, int q, float4 acc) {
+  int xr[U];
+  float w4[U];
+  float4 v4[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) xr[u] = HAS_XIDX ? a.xidx[q + u] : q + u;
+  if (MAPPED) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) xr[u] = a.xmap[xr[u]];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int safe = (MAPPED && xr[u] < 0) ? 0 : xr[u];
+    v4[u] = *reinterpret_cast<const float4*>(xcol + int64_t(safe) * a.D);
+    w4[u] = WEIGHTED ? a.w[HAS_WIDX ? a.widx[q + u] : q + u] : 1.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);   // all U row loads are in flight before the first add (hipcc would interleave)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float4 nxt = accum<WEIGHTED>(acc, v4[u], w4[u]);
+    if (!MAPPED || xr[u] >= 0) acc = nxt;   // a select, not a branch
+  }
+  return acc;
+}
+
+// LPR lanes cooperate on one output row; each lane owns float4 column groups c4, c4+LPR, ...
+// DEEP: coarse levels (few rows, up to ~170 edges each): the critical path is (edges / batch) dependent HBM round
+// trips of the longest row, so batch 32 rows (128 registers; occupancy is irrelevant there).
+template <int LPR, bool WEIGHTED, bool MAPPED, bool DEEP, bool HAS_XIDX, bool HAS_WIDX>
+__device__ __forceinline__ void rowsum_body(const RowSumArgs& a) {
   const int64_t worker = (int64_t(blockIdx.x) * 256 + threadIdx.x) / LPR;
   const int lane = threadIdx.x % LPR;
   if (worker >= int64_t(a.B) * a.n_out) return;
@@ -56,37 +90,27 @@ __global__ __launch_bounds__(256) void k_rowsum_v4(RowSumArgs a) {
   const int d4 = a.D >> 2;
   for (int c4 = lane; c4 < d4; c4 += LPR) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xcol = xb + c4 * 4;
     int q = q0;
-    // U independent row loads in flight, summed strictly in edge order (coarse levels have rows of 30-60 edges
-    // and few rows: without enough loads in flight the kernel is pure latency)
-#define BSMS_ROWSUM_BATCH(U)                                                                                  \
-    for (; q + U <= q1; q += U) {                                                                             \
-      float4 v4[U];                                                                                           \
-      float w4[U];                                                                                            \
-      bool live[U];                                                                                           \
-      _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                         \
-        int xr = a.xidx ? a.xidx[q + u] : q + u;                                                              \
-        if (MAPPED) xr = a.xmap[xr];                                                                          \
-        live[u] = !MAPPED || xr >= 0;                                                                         \
-        v4[u] = live[u] ? *reinterpret_cast<const float4*>(xb + int64_t(xr) * a.D + c4 * 4)                   \
-                        : make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-        w4[u] = WEIGHTED ? a.w[a.widx ? a.widx[q + u] : q + u] : 1.f;                                         \
-      }                                                                                                       \
-      _Pragma("unroll") for (int u = 0; u < U; ++u)                                                           \
-        if (live[u]) acc = accum<WEIGHTED>(acc, v4[u], w4[u]);                                                \
-    }
-    BSMS_ROWSUM_BATCH(8)
-    BSMS_ROWSUM_BATCH(2)
-#undef BSMS_ROWSUM_BATCH
-    for (; q < q1; ++q) {
-      int xr = a.xidx ? a.xidx[q] : q;
-      if (MAPPED) xr = a.xmap[xr];
-      if (MAPPED && xr < 0) continue;
-      float4 v = *reinterpret_cast<const float4*>(xb + int64_t(xr) * a.D + c4 * 4);
-      float w = WEIGHTED ? a.w[a.widx ? a.widx[q] : q] : 1.f;
-      acc = accum<WEIGHTED>(acc, v, w);
-    }
+    if (DEEP)
+      for (; q + 32 <= q1; q += 32) acc = rowsum_batch<32, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
+    for (; q + 8 <= q1; q += 8) acc = rowsum_batch<8, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
+    for (; q + 2 <= q1; q += 2) acc = rowsum_batch<2, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
+    for (; q < q1; ++q) acc = rowsum_batch<1, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
     *reinterpret_cast<float4*>(ob + c4 * 4) = acc;
+  }
+}
+
+template <int LPR, bool WEIGHTED, bool MAPPED, bool DEEP = false>
+__global__ __launch_bounds__(256) void k_rowsum_v4(RowSumArgs a) {
+  // the optional index arrays are tested once (uniform), not per slot
+  const bool hx = a.xidx != nullptr, hw = WEIGHTED && a.widx != nullptr;
+  if (hx) {
+    if (hw) rowsum_body<LPR, WEIGHTED, MAPPED, DEEP, true, WEIGHTED>(a);
+    else rowsum_body<LPR, WEIGHTED, MAPPED, DEEP, true, false>(a);
+  } else {
+    if (hw) rowsum_body<LPR, WEIGHTED, MAPPED, DEEP, false, WEIGHTED>(a);
+    else rowsum_body<LPR, WEIGHTED, MAPPED, DEEP, false, false>(a);
   }
 }
 
@@ -115,6 +139,9 @@ __global__ __launch_bounds__(256) void k_rowsum_scalar(RowSumArgs a) {
   a.out[b * a.out_bstride + int64_t(r) * a.D + c] = acc;
 }
 
+// below this many lanes the chip is under-filled (256 CUs x 2048 threads) and latency, not bandwidth, is the limit
+constexpr int64_t kDeepBelowThreads = 400 * 1024;
+
 template <bool WEIGHTED, bool MAPPED>
 int launch_rowsum_wm(const RowSumArgs& a, hipStream_t s) {
   const int64_t workers = int64_t(a.B) * a.n_out;
@@ -124,9 +151,15 @@ int launch_rowsum_wm(const RowSumArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_rowsum_scalar<WEIGHTED, MAPPED>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, a);
   } else {
     const int d4 = a.D / 4;
-#define BSMS_RS(L)                                                                                      \
-  hipLaunchKernelGGL((k_rowsum_v4<L, WEIGHTED, MAPPED>), dim3((unsigned)ceil_div(workers * L, 256)), \
-                     dim3(256), 0, s, a)
+#define BSMS_RS(L)                                                                                              \
+  do {                                                                                                          \
+    if (workers * L < kDeepBelowThreads)                                                                        \
+      hipLaunchKernelGGL((k_rowsum_v4<L, WEIGHTED, MAPPED, true>), dim3((unsigned)ceil_div(workers * L, 256)),  \
+                         dim3(256), 0, s, a);                                                                   \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_rowsum_v4<L, WEIGHTED, MAPPED, false>), dim3((unsigned)ceil_div(workers * L, 256)), \
+                         dim3(256), 0, s, a);                                                                   \
+  } while (0)
     if (d4 <= 1) BSMS_RS(1);
     else if (d4 <= 2) BSMS_RS(2);
     else if (d4 <= 4) BSMS_RS(4);
