@@ -26,4 +26,4 @@ for lvl, (n, e) in enumerate(wl["levels"]):
             ts.append(a.elapsed_time(b) * 1e3)
         ts.sort(); res[mode] = ts[len(ts) // 2]
     mb = (8 * e + 8 * n) * 512 / 1e6
-    print(f"level {lvl}: N={n} E={e}  {mb:6.1f} MB  warm {res['warm']:6.1f} us ({mb / res["warm"]:.2f} TB/s)  flushed {res['flushed']:6.1f} us ({mb / res["flushed"]:.2f} TB/s)")
+    print(f"level {lvl}: N={n} E={e}  {mb:6.1f} MB  warm {res['warm']:6.1f} us ({mb / res['warm']:.2f} TB/s)  flushed {res['flushed']:6.1f} us ({mb / res['flushed']:.2f} TB/s)")
