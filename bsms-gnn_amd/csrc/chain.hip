@@ -66,31 +66,30 @@ __device__ __forceinline__ void zero_tile(f32x4 (&v)[NB]) {
   for (int t = 0; t < NB; ++t) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// lane's row pointer (nullptr = row out of range -> zeros); 4 lanes of a row read 64 contiguous bytes
+// lane's row pointer; 4 lanes of a row read 64 contiguous bytes.  UNCONDITIONAL on purpose: a predicated load costs
+// a branch, a zero-fill and a vmcnt wait per 16 bytes (hipcc then serialises a row into eight dependent round
+// trips).  Lanes past the last row are pointed at row 0 by the caller; their results are never stored.
 template <int NB>
 __device__ __forceinline__ void load_rows(f32x4 (&v)[NB], const float* row, int g) {
 #pragma unroll
-  for (int t = 0; t < NB; ++t) {
-    const float4 x = row ? *reinterpret_cast<const float4*>(row + 16 * t + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v[t] = f32x4{x.x, x.y, x.z, x.w};
-  }
+  for (int t = 0; t < NB; ++t) v[t] = *reinterpret_cast<const f32x4*>(row + 16 * t + 4 * g);
 }
 
+// `base` is the tensor (wave-uniform, nullable), `off` this lane's row offset in floats (negative: lane past the last
+// row, nothing is stored).  Callers keep ONE 64-bit per-lane value (the offset) instead of a pointer per tensor.
 template <int NB, bool ACCUM>
-__device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* row, int g, int mode = 0) {
-  if (!row) return;
+__device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* base, int64_t off, int g, int mode = 0) {
+  if (!base || off < 0) return;
+  float* row = base + off;
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
-    float4* p = reinterpret_cast<float4*>(row + 16 * t + 4 * g);
-    float4 x = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
-    if (ACCUM) {
-      const float4 o = *p;
-      x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
-    }
+    f32x4* p = reinterpret_cast<f32x4*>(row + 16 * t + 4 * g);
+    f32x4 x = v[t];
+    if (ACCUM) x += *p;
     if (mode == 1) {
-      __builtin_nontemporal_store(v[t], reinterpret_cast<f32x4*>(p));
+      __builtin_nontemporal_store(x, p);
     } else if (mode == 2) {
-      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v[t]) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
     } else {
       *p = x;
     }
@@ -136,7 +135,8 @@ struct Ring {
   static constexpr int CH4 = CHF / 4;                         // float4 per chunk
   static constexpr int PER = CHF / 256;                       // LDS-DMA instructions (1 KB each) per chunk
   static constexpr int NR = 3;                                // ring depth
-  static constexpr size_t lds_bytes = size_t(NR) * CHF * sizeof(float);
+  static constexpr int SIDE_FLOATS = 8 * D;                   // side table after the ring: the edge MLP's fiber weights
+  static constexpr size_t lds_bytes = size_t(NR) * CHF * sizeof(float) + SIDE_FLOATS * sizeof(float);
   static_assert(CHF % 256 == 0 && PER < 64, "chunk = whole LDS-DMA instructions, countable by vmcnt");
   static_assert(NB % 2 == 0, "K blocks are pairs of 16-feature blocks");
 };
@@ -154,10 +154,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 
 // the loader wave's whole life
 template <int NB>
-__device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles) {
+__device__ __forceinline__ float* ring_side(float4* lds) { return reinterpret_cast<float*>(lds + Ring<NB>::NR * Ring<NB>::CH4); }
+
+// `side` (nullable, 8*D floats in HBM): copied once into the side table; the compute waves wait for it at one extra
+// barrier before their first tile.
+template <int NB>
+__device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles,
+                                           const float* side = nullptr) {
   using R = Ring<NB>;
   __builtin_amdgcn_s_setprio(3);                   // the loader must never be the wave the others wait for
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+  if (side) {
+    const unsigned dst = lds0 + unsigned(R::NR) * unsigned(R::CHF * sizeof(float));
+#pragma unroll
+    for (int i = 0; i < R::SIDE_FLOATS / 256; ++i) glds16(reinterpret_cast<const float4*>(side) + i * 64 + lane, dst + i * 1024);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
   const int my_tiles = (ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
   const int per_tile = nseq * R::NCH, total = my_tiles * per_tile;
   int is = 0, ic = 0, islot = 0;                   // next chunk to issue: sequence entry, chunk in it, ring slot
@@ -207,15 +219,16 @@ __device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
 // One Linear on the compute waves: acc[t] (+)= sum_k W[16t + ., k] * act[k] with the six bf16 partial products.
 // `slot` = ring slot of the stage's first chunk (advanced here).  `from_header`: start acc from the bias in the
 // header of the stage's first chunk instead of accumulating onto the caller's acc.
-// `store_row` (nullable): this lane's row of an HBM tensor that receives `act`; issued right after the split so
-// the store has the whole stage to drain.  All compute waves of the workgroup must call this together.
+// `store_base` (nullable, uniform) + `store_off`: HBM tensor / this lane's row offset that receives `act`; issued
+// right after the split so the store has the whole stage to drain.  All compute waves of the workgroup must call this together.
 template <int NB>
 __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
-                                           bool from_header, float* store_row = nullptr, int store_mode = 0) {
+                                           bool from_header, float* store_base = nullptr, int64_t store_off = -1,
+                                           int store_mode = 0) {
   using R = Ring<NB>;
   u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
   split_tile<NB>(act, bh, bm, bl);
-  store_rows<NB, false>(act, store_row, lane >> 4, store_mode);
+  store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     lds_barrier();                                           // chunk has landed (and my reads of the last one are done)
@@ -230,23 +243,31 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
       }
     }
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
-    // two accumulators interleaved so that back-to-back MFMAs are independent; smallest terms first
+    // two accumulators interleaved so that back-to-back MFMAs are independent; one weight plane at a time (each
+    // fragment pair is dead after its products: 8 fragment registers live + the next pair in flight)
 #pragma unroll
     for (int t = 0; t < NB; t += 2) {
-      const float4 h0 = body[(t * 3 + 0) * 64], m0 = body[(t * 3 + 1) * 64], l0 = body[(t * 3 + 2) * 64];
-      const float4 h1 = body[(t * 3 + 3) * 64], m1 = body[(t * 3 + 4) * 64], l1 = body[(t * 3 + 5) * 64];
-      acc[t] = mma(l0, bh[c], acc[t]);
-      acc[t + 1] = mma(l1, bh[c], acc[t + 1]);
-      acc[t] = mma(h0, bl[c], acc[t]);
-      acc[t + 1] = mma(h1, bl[c], acc[t + 1]);
-      acc[t] = mma(m0, bm[c], acc[t]);
-      acc[t + 1] = mma(m1, bm[c], acc[t + 1]);
-      acc[t] = mma(m0, bh[c], acc[t]);
-      acc[t + 1] = mma(m1, bh[c], acc[t + 1]);
-      acc[t] = mma(h0, bm[c], acc[t]);
-      acc[t + 1] = mma(h1, bm[c], acc[t + 1]);
-      acc[t] = mma(h0, bh[c], acc[t]);
-      acc[t + 1] = mma(h1, bh[c], acc[t + 1]);
+      {
+        const float4 h0 = body[(t * 3 + 0) * 64], h1 = body[(t * 3 + 3) * 64];
+        acc[t] = mma(h0, bl[c], acc[t]);
+        acc[t + 1] = mma(h1, bl[c], acc[t + 1]);
+        acc[t] = mma(h0, bm[c], acc[t]);
+        acc[t + 1] = mma(h1, bm[c], acc[t + 1]);
+        acc[t] = mma(h0, bh[c], acc[t]);
+        acc[t + 1] = mma(h1, bh[c], acc[t + 1]);
+      }
+      {
+        const float4 m0 = body[(t * 3 + 1) * 64], m1 = body[(t * 3 + 4) * 64];
+        acc[t] = mma(m0, bm[c], acc[t]);
+        acc[t + 1] = mma(m1, bm[c], acc[t + 1]);
+        acc[t] = mma(m0, bh[c], acc[t]);
+        acc[t + 1] = mma(m1, bh[c], acc[t + 1]);
+      }
+      {
+        const float4 l0 = body[(t * 3 + 2) * 64], l1 = body[(t * 3 + 5) * 64];
+        acc[t] = mma(l0, bh[c], acc[t]);
+        acc[t + 1] = mma(l1, bh[c], acc[t + 1]);
+      }
     }
   }
 }
@@ -287,14 +308,23 @@ __device__ __forceinline__ float dot_features(const f32x4 (&v)[NB], const float*
 }
 
 // -------------------------------------------------------------------------------- forward chain
-template <int NB, int IN, int OUT>
+// TIMING (experiments, profiles/tile_timeline.py): phase stamps of wave 0; a separate instantiation so that the
+// production kernel carries none of it.
+template <int NB, int IN, int OUT, bool TIMING = false>
 __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   if (wave == kComputeWaves) {  // loader wave (uniform branch)
-    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles);
+    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
     return;
+  }
+  // IN_EDGE: the fiber weights are read from the LDS side table (read from HBM/L2 they cost one dependent round
+  // trip per 16 bytes: 24 of them per tile, the largest part of the input stage)
+  const float* w0t = a.w0t;
+  if (IN == IN_EDGE) {
+    lds_barrier();
+    w0t = ring_side<NB>(lds);
   }
   int slot = 0;  // ring slot of the next chunk; runs on across this workgroup's tiles exactly like the loader's
   // Persistent workgroups: the grid is sized to what the chip holds at once and strides over the tiles, so a CU
@@ -303,12 +333,14 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
   const int64_t row = int64_t(tile) * kTileRows + wave * 16 + (lane & 15);
   const bool live = row < a.R;
+  const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
+  const int64_t roff = live ? row * D : -1;  // row offset for stores; negative = no store
   int stamp_i = 0;
   auto stamp = [&]() {  // experiments: wave 0 / lane 0 records the shader clock at phase boundaries
-    if (a.timing && tid == 0 && stamp_i < 16) a.timing[int64_t(tile) * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
+    if (TIMING && a.timing && tid == 0 && stamp_i < 16) a.timing[int64_t(tile) * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
   };
   stamp();
-  if (a.timing && tid == 0) {
+  if (TIMING && a.timing && tid == 0) {
     a.timing[int64_t(tile) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
     a.timing[int64_t(tile) * 16 + 13] = (uint64_t(__builtin_amdgcn_s_getreg(63508)) << 32) |  // XCC_ID
                                         uint32_t(__builtin_amdgcn_s_getreg(63492));             // HW_ID
@@ -318,59 +350,64 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
 
   // ---- input stage
   if (IN == IN_ROWS || IN == IN_ROWS2) {
-    load_rows<NB>(act, live ? a.x + row * D : nullptr, lg);
+    load_rows<NB>(act, a.x + rowc * D, lg);
   } else if (IN == IN_SMALL) {
-    if (live) {
-      load_features<NB>(act, a.bias_in, lg);
-      for (int k = 0; k < a.K0; ++k) axpy_features<NB>(act, a.w0t + k * D, a.x[row * a.K0 + k], lg);
-      relu_into<NB>(act, act);
-    } else {
-      zero_tile<NB>(act);
-    }
+    load_features<NB>(act, a.bias_in, lg);
+    for (int k = 0; k < a.K0; ++k) axpy_features<NB>(act, w0t + k * D, a.x[rowc * a.K0 + k], lg);
+    relu_into<NB>(act, act);
   } else {  // IN_EDGE: relu(Ps[src] + Pd[dst] + Wf . [pos_i - pos_j, |pos_i - pos_j|])   (ops/basic.py:70-92)
-    if (live) {
-      const int b = int(row / a.E), q = int(row - int64_t(b) * a.E);
+    {
+      const int b = int(rowc / a.E), q = int(rowc - int64_t(b) * a.E);
       const int i = a.src[q], j = a.dst[q];
       load_rows<NB>(act, a.Ps + (int64_t(b) * a.N + i) * D, lg);
       load_rows<NB>(acc, a.Pd + (int64_t(b) * a.N + j) * D, lg);
+      const float* pb = a.pos + b * a.pos_bstride;
+      float pi[7], pj[7];  // check_gmp: p <= 7
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        const int cc = c < a.p ? c : 0;   // uniform clamp: the loads stay unconditional
+        pi[c] = pb[int64_t(i) * a.p + cc];
+        pj[c] = pb[int64_t(j) * a.p + cc];
+      }
+      // all gathers of the tile are in flight before the first use
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < NB; ++t) act[t] += acc[t];
-      const float* pb = a.pos + b * a.pos_bstride;
       float n2 = 0.f;
-      for (int c = 0; c < a.p; ++c) {
-        const float rel = pb[int64_t(i) * a.p + c] - pb[int64_t(j) * a.p + c];
-        n2 = fmaf(rel, rel, n2);
-        axpy_features<NB>(act, a.w0t + c * D, rel, lg);
-      }
-      axpy_features<NB>(act, a.w0t + a.p * D, sqrtf(n2), lg);
+#pragma unroll
+      for (int c = 0; c < 7; ++c)
+        if (c < a.p) {
+          const float rel = pi[c] - pj[c];
+          n2 = fmaf(rel, rel, n2);
+          axpy_features<NB>(act, w0t + c * D, rel, lg);
+        }
+      axpy_features<NB>(act, w0t + a.p * D, sqrtf(n2), lg);
       relu_into<NB>(act, act);
-    } else {
-      zero_tile<NB>(act);
     }
   }
 
   // ---- MFMA stages.  The activation entering a stage is stored to HBM from inside that stage (mfma_stage).
   stamp();            // input stage done
   stamp();
-  float* pending = ((IN == IN_SMALL || IN == IN_EDGE) && live && a.store_in) ? a.store_in + row * D : nullptr;
-  if (a.nstage == 0 && pending) store_rows<NB, false>(act, pending, lg);
+  float* pending = (IN == IN_SMALL || IN == IN_EDGE) ? a.store_in : nullptr;   // uniform
+  if (a.nstage == 0) store_rows<NB, false>(act, pending, roff, lg);
   for (int l = 0; l < a.nstage; ++l) {
-    mfma_stage<NB>(acc, act, lds, slot, lane, true, pending, a.store_mode);  // acc = bias + W act
+    mfma_stage<NB>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode);  // acc = bias + W act
     stamp();          // stage l done
     pending = nullptr;
     if (IN == IN_ROWS2 && l == 0) {
-      load_rows<NB>(act, live ? a.x2 + row * D : nullptr, lg);
+      load_rows<NB>(act, a.x2 + rowc * D, lg);
       mfma_stage<NB>(acc, act, lds, slot, lane, false);
     }
     const bool last = (l == a.nstage - 1);
     if (!last || OUT == OUT_SMALL) {
       relu_into<NB>(act, acc);
-      if (!last) pending = (live && a.store[l]) ? a.store[l] + row * D : nullptr;
-      else if (live && a.store[l]) store_rows<NB, false>(act, a.store[l] + row * D, lg);
+      if (!last) pending = a.store[l];
+      else store_rows<NB, false>(act, a.store[l], roff, lg);
     }
   }
   stamp();
-  if (a.timing && tid == 0) a.timing[int64_t(tile) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+  if (TIMING && a.timing && tid == 0) a.timing[int64_t(tile) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
   if (!live) continue;
 
   // ---- output
@@ -390,21 +427,21 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     for (int t = 0; t < NB; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] *= rstd;
-    if (a.yln) store_rows<NB, false>(acc, a.yln + row * D, lg);
+    store_rows<NB, false>(acc, a.yln, roff, lg);
     if (a.rstd && lg == 0) a.rstd[row] = rstd;
     if (a.resid) {
       load_rows<NB>(act, a.resid + row * D, lg);
 #pragma unroll
       for (int t = 0; t < NB; ++t) acc[t] += act[t];
     }
-    store_rows<NB, false>(acc, a.y + row * D, lg, a.out_mode);
-    if (a.timing && tid == 0) {
+    store_rows<NB, false>(acc, a.y, roff, lg, a.out_mode);
+    if (TIMING && a.timing && tid == 0) {
       __builtin_amdgcn_s_waitcnt(0);  // experiments: all of this wave's stores acknowledged
       a.timing[int64_t(tile) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
     }
   } else if (OUT == OUT_PLAIN) {
-    if (a.accumulate) store_rows<NB, true>(acc, a.y + row * D, lg);
-    else store_rows<NB, false>(acc, a.y + row * D, lg);
+    if (a.accumulate) store_rows<NB, true>(acc, a.y, roff, lg);
+    else store_rows<NB, false>(acc, a.y, roff, lg);
   } else {  // OUT_SMALL: the narrow last Linear (decoder, models/model.py:22) on the VALU
     for (int c = 0; c < a.C; ++c) {
       const float v = dot_features<NB>(act, a.wout + c * D, lg);
@@ -440,61 +477,63 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {  // persistent workgroups (see k_chain_fwd)
   const int64_t row = int64_t(tile) * kTileRows + wave * 16 + (lane & 15);
   const bool live = row < a.R;
+  const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
+  const int64_t roff = live ? row * D : -1;  // row offset for stores; negative = no store
 
   f32x4 g[NB], acc[NB];
-  zero_tile<NB>(g);
-  if (live) {
-    if (GIN == G_SMALL) {  // g = (dy . W_out) masked by the last hidden activation
-      for (int c = 0; c < a.C; ++c) axpy_features<NB>(g, a.wout + c * D, a.dy[row * a.C + c], lg);
-      mask_by<NB>(g, a.mask_in + row * D, lg);
+  if (GIN == G_SMALL) {  // g = (dy . W_out) masked by the last hidden activation
+    zero_tile<NB>(g);
+    for (int c = 0; c < a.C; ++c) axpy_features<NB>(g, a.wout + c * D, a.dy[rowc * a.C + c], lg);
+    mask_by<NB>(g, a.mask_in + rowc * D, lg);
+  } else {
+    const float* dyrow;
+    if (GIN == G_EDGE_LN) {  // autograd of scatter_sum: gather the node gradient by target
+      const int b = int(rowc / a.E), q = int(rowc - int64_t(b) * a.E);
+      dyrow = a.dy + (int64_t(b) * a.N + a.dst[q]) * D;
     } else {
-      const float* dyrow;
-      if (GIN == G_EDGE_LN) {  // autograd of scatter_sum: gather the node gradient by target
-        const int b = int(row / a.E), q = int(row - int64_t(b) * a.E);
-        dyrow = a.dy + (int64_t(b) * a.N + a.dst[q]) * D;
-      } else {
-        dyrow = a.dy + row * D;
-      }
-      load_rows<NB>(g, dyrow, lg);
-      load_rows<NB>(acc, a.yln + row * D, lg);  // acc = normalised output y
-      // LayerNorm backward (no affine): dz = rstd * (dy - mean(dy) - y * mean(dy * y))
-      const float m1 = row_sum<NB>(g) * (1.f / D);
-      float s2 = 0.f;
-#pragma unroll
-      for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s2 = fmaf(g[t][r], acc[t][r], s2);
-      s2 = group_sum(s2);
-      const float m2 = s2 * (1.f / D), rs = a.rstd[row];
-#pragma unroll
-      for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g[t][r] = rs * (g[t][r] - m1 - acc[t][r] * m2);
+      dyrow = a.dy + rowc * D;
     }
+    load_rows<NB>(g, dyrow, lg);
+    load_rows<NB>(acc, a.yln + rowc * D, lg);  // acc = normalised output y
+    const float rs = a.rstd[rowc];
+    __builtin_amdgcn_sched_barrier(0);         // all 17 loads in flight before the first use (see k_chain_fwd)
+    // LayerNorm backward (no affine): dz = rstd * (dy - mean(dy) - y * mean(dy * y))
+    const float m1 = row_sum<NB>(g) * (1.f / D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s2 = fmaf(g[t][r], acc[t][r], s2);
+    s2 = group_sum(s2);
+    const float m2 = s2 * (1.f / D);
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[t][r] = rs * (g[t][r] - m1 - acc[t][r] * m2);
   }
   // The gradient entering a stage is stored to HBM from inside that stage (mfma_stage), so the store has a whole
   // stage to drain before the next vmcnt wait (the ReLU-mask rows at the end of the stage).
-  float* pending = (live && a.gstore[0]) ? a.gstore[0] + row * D : nullptr;
+  float* pending = a.gstore[0];   // uniform
 
   for (int k = 0; k < a.nstage; ++k) {
     zero_tile<NB>(acc);
-    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, a.store_mode);
-    const bool masked = live && a.mask[k];
-    if (masked) load_rows<NB>(g, a.mask[k] + row * D, lg);            // g is consumed: reuse it for the mask rows
+    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode);
+    const bool masked = a.mask[k] != nullptr;                          // uniform
+    if (masked) load_rows<NB>(g, a.mask[k] + rowc * D, lg);           // g is consumed: reuse it for the mask rows
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) g[t][r] = (!masked || g[t][r] > 0.f) ? acc[t][r] : 0.f;
-    pending = (live && a.gstore[k + 1]) ? a.gstore[k + 1] + row * D : nullptr;
+    pending = a.gstore[k + 1];
   }
 
   if (FIRST != F_NONE) {
     zero_tile<NB>(acc);
-    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending);
+    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff);
     pending = nullptr;
-    if (live && a.dres) {
+    if (a.dres) {
       f32x4 r[NB];
-      load_rows<NB>(r, a.dres + row * D, lg);
+      load_rows<NB>(r, a.dres + rowc * D, lg);
 #pragma unroll
       for (int t = 0; t < NB; ++t) acc[t] += r[t];
     }
@@ -502,15 +541,13 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
       f32x4 acc2[NB];
       zero_tile<NB>(acc2);
       mfma_stage<NB>(acc2, g, lds, slot, lane, false);
-      if (live) {
-        store_rows<NB, false>(acc, a.dx + row * D, lg);
-        store_rows<NB, false>(acc2, a.dx2 + row * D, lg);
-      }
-    } else if (live) {
-      store_rows<NB, false>(acc, a.dx + row * D, lg);
+      store_rows<NB, false>(acc, a.dx, roff, lg);
+      store_rows<NB, false>(acc2, a.dx2, roff, lg);
+    } else {
+      store_rows<NB, false>(acc, a.dx, roff, lg);
     }
   }
-  if (pending) store_rows<NB, false>(g, pending, lg);
+  store_rows<NB, false>(g, pending, roff, lg);
   }  // tile loop
 }
 
@@ -545,7 +582,18 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve %zu bytes of LDS", lds);
   a.ntiles = (int)ceil_div(a.R, kTileRows);
-  hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+  bool launched = false;
+  if constexpr (NB == 8 && IN == IN_EDGE) {   // the only instantiation with stamps
+    if (a.timing) {
+      static const hipError_t tattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+      BSMS_REQUIRE(tattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (timing build)");
+      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, true>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+      launched = true;
+    }
+  }
+  if (!launched)
+    hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
