@@ -36,6 +36,10 @@ constexpr int kComputeWaves = 4;                       // compute waves per work
 constexpr int kTileRows = kComputeWaves * 16;          // rows of x per workgroup
 constexpr int kChainThreads = (kComputeWaves + 1) * 64;  // + 1 loader wave
 constexpr int kChunkHdrFloats = 256;                     // 1 KB chunk header (bias)
+// A saved activation [rows, D] is followed by its ReLU sign bits, one bit per element packed per (row, lane group):
+// the backward chain masks gradients from 16 bytes per row instead of re-reading 4 D bytes.
+constexpr size_t mask_words_per_row(int64_t D) { return size_t(4) * (D <= 128 ? 1 : D / 128); }
+constexpr size_t act_floats(size_t rows, int64_t D) { return rows * size_t(D) + rows * mask_words_per_row(D); }
 // floats in one weight pack of a D x D Linear (bf16 x 3 planes + headers)
 constexpr size_t pack_floats(int64_t D) { return size_t(D / 32) * (kChunkHdrFloats + size_t(D / 16) * 768); }
 
@@ -53,7 +57,7 @@ struct ChainFwdArgs {
   int K0;            // IN_SMALL: input width; IN_EDGE: p+1
   const float* w0t;  // IN_SMALL: W0^T [K0][D]; IN_EDGE: fiber weights^T [p+1][D]
   const float* bias_in;  // IN_SMALL: b0 [D]
-  float* store_in;   // IN_SMALL/IN_EDGE: activation after the input stage [R,D] (nullable)
+  float* store_in;   // IN_SMALL/IN_EDGE: activation after the input stage, act_floats(R, D) floats (nullable)
   const int32_t *src, *dst;  // IN_EDGE: plan-order endpoints
   int32_t E, N;
   const float *Ps, *Pd;      // IN_EDGE: per-node pre-projections [B*N, D]
@@ -64,7 +68,7 @@ struct ChainFwdArgs {
   int nstage;
   const float4* wp[kMaxStages];  // packs (the Linear's bias travels in the pack header, see PackDesc)
   const float4* wp0b;  // IN_ROWS2: pack for x2 in stage 0
-  float* store[kMaxStages];  // post-ReLU activation of stage l (nullable)
+  float* store[kMaxStages];  // post-ReLU activation of stage l, act_floats(R, D) floats: values + sign bits (nullable)
   // ---- output
   float* y;           // OUT_LN / OUT_PLAIN: [R,D]; OUT_SMALL: [R,C]
   float* yln;         // OUT_LN: normalised output before the residual (nullable)
@@ -95,7 +99,7 @@ struct ChainBwdArgs {
   const float* mask_in;  // G_SMALL: activation masking the VALU-produced gradient
   int nstage;
   const float4* wpt[kMaxStages];  // transposed packs, execution order (top layer first)
-  const float* mask[kMaxStages];  // activation whose sign masks the OUTPUT of stage k
+  const float* mask[kMaxStages];  // saved activation (act_floats layout) whose sign BITS mask the output of stage k
   float* gstore[kMaxStages + 1];  // [0]: gradient entering stage 0; [k+1]: output of stage k (nullable)
   // ---- first-layer input gradient
   const float4 *wh0, *wh1;

@@ -96,6 +96,27 @@ __device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* base, in
   }
 }
 
+// ReLU sign bits of this lane's 4 NB values: bit (4 t + r) of word (4 t + r) / 32
+template <int NB>
+constexpr int mask_words() { return NB <= 8 ? 1 : NB / 8; }
+
+template <int NB>
+__device__ __forceinline__ void store_mask_bits(const f32x4 (&v)[NB], float* act_base, int64_t R, int64_t off, int g) {
+  if (!act_base || off < 0) return;
+  constexpr int D = NB * 16, W = mask_words<NB>();
+  unsigned* bits = reinterpret_cast<unsigned*>(act_base + R * D) + (off / D) * (4 * W) + g * W;
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 32 && 32 * w + k < 4 * NB; ++k) {
+      const int e = 32 * w + k;
+      m |= (v[e >> 2][e & 3] > 0.f) ? (1u << k) : 0u;
+    }
+    bits[w] = m;
+  }
+}
+
 // bias (or any per-feature vector) in this lane's feature order
 template <int NB>
 __device__ __forceinline__ void load_features(f32x4 (&v)[NB], const float* vec, int g) {
@@ -224,11 +245,12 @@ __device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
 template <int NB>
 __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
                                            bool from_header, float* store_base = nullptr, int64_t store_off = -1,
-                                           int store_mode = 0) {
+                                           int store_mode = 0, int64_t mask_rows = 0) {
   using R = Ring<NB>;
   u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
   split_tile<NB>(act, bh, bm, bl);
   store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
+  if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);   // saved activation: + sign bits
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     lds_barrier();                                           // chunk has landed (and my reads of the last one are done)
@@ -390,9 +412,12 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   stamp();            // input stage done
   stamp();
   float* pending = (IN == IN_SMALL || IN == IN_EDGE) ? a.store_in : nullptr;   // uniform
-  if (a.nstage == 0) store_rows<NB, false>(act, pending, roff, lg);
+  if (a.nstage == 0) {
+    store_rows<NB, false>(act, pending, roff, lg);
+    store_mask_bits<NB>(act, pending, a.R, roff, lg);
+  }
   for (int l = 0; l < a.nstage; ++l) {
-    mfma_stage<NB>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode);  // acc = bias + W act
+    mfma_stage<NB>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode, a.R);  // acc = bias + W act
     stamp();          // stage l done
     pending = nullptr;
     if (IN == IN_ROWS2 && l == 0) {
@@ -516,14 +541,18 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   float* pending = a.gstore[0];   // uniform
 
   for (int k = 0; k < a.nstage; ++k) {
+    // ReLU sign bits of the activation that masks this stage's output: one small load, issued before the stage
+    unsigned mbits[mask_words<NB>()];
+#pragma unroll
+    for (int w = 0; w < mask_words<NB>(); ++w)
+      mbits[w] = a.mask[k] ? reinterpret_cast<const unsigned*>(a.mask[k] + a.R * D)[rowc * (4 * mask_words<NB>()) + lg * mask_words<NB>() + w]
+                           : 0xffffffffu;
     zero_tile<NB>(acc);
     mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode);
-    const bool masked = a.mask[k] != nullptr;                          // uniform
-    if (masked) load_rows<NB>(g, a.mask[k] + rowc * D, lg);           // g is consumed: reuse it for the mask rows
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) g[t][r] = (!masked || g[t][r] > 0.f) ? acc[t][r] : 0.f;
+      for (int r = 0; r < 4; ++r) g[t][r] = ((mbits[(4 * t + r) >> 5] >> ((4 * t + r) & 31)) & 1u) ? acc[t][r] : 0.f;
     pending = a.gstore[k + 1];
   }
 

@@ -63,12 +63,12 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
   if (training)
-    for (int l = 0; l < H; ++l) s.e_act[l] = c.take(re * D);
+    for (int l = 0; l < H; ++l) s.e_act[l] = c.take(act_floats(re, D));
   s.e_y = c.take(re * D);
   if (training) s.e_rstd = c.take(re);
   s.aggr = c.take(rn * D);
   if (training) {
-    for (int l = 0; l < H; ++l) s.n_act[l] = c.take(rn * D);
+    for (int l = 0; l < H; ++l) s.n_act[l] = c.take(act_floats(rn, D));
     s.n_yln = c.take(rn * D);
     s.n_rstd = c.take(rn);
   }
@@ -350,7 +350,7 @@ MlpSaved carve_mlp_saved(void* base, int64_t R, int64_t D, int H, bool training 
   Carver c(base);
   MlpSaved s{};
   if (training) {
-    for (int l = 0; l < H; ++l) s.act[l] = c.take(size_t(R) * D);
+    for (int l = 0; l < H; ++l) s.act[l] = c.take(act_floats(size_t(R), D));
     s.yln = c.take(size_t(R) * D);
     s.rstd = c.take(size_t(R));
   }
