@@ -44,7 +44,7 @@ constexpr size_t act_floats(size_t rows, int64_t D) { return rows * size_t(D) + 
 constexpr size_t pack_floats(int64_t D) { return size_t(D / 32) * (kChunkHdrFloats + size_t(D / 16) * 768); }
 
 enum ChainIn { IN_ROWS = 0, IN_ROWS2 = 1, IN_SMALL = 2, IN_EDGE = 3 };
-enum ChainOut { OUT_LN = 0, OUT_PLAIN = 1, OUT_SMALL = 2 };
+enum ChainOut { OUT_LN = 0, OUT_PLAIN = 1, OUT_SMALL = 2, OUT_PLAIN2 = 3 };  // PLAIN2: stage 0 -> y, stage 1 -> y2, same input
 enum GradIn { G_ROWS_LN = 0, G_EDGE_LN = 1, G_SMALL = 2 };
 enum GradFirst { F_NONE = 0, F_HEADS1 = 1, F_HEADS2 = 2 };
 
@@ -71,6 +71,7 @@ struct ChainFwdArgs {
   float* store[kMaxStages];  // post-ReLU activation of stage l, act_floats(R, D) floats: values + sign bits (nullable)
   // ---- output
   float* y;           // OUT_LN / OUT_PLAIN: [R,D]; OUT_SMALL: [R,C]
+  float* y2;          // OUT_PLAIN2: second head [R,D]
   float* yln;         // OUT_LN: normalised output before the residual (nullable)
   float* rstd;        // OUT_LN: [R] (nullable)
   const float* resid; // OUT_LN: residual rows added to y (nullable)

@@ -416,6 +416,13 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     store_rows<NB, false>(act, pending, roff, lg);
     store_mask_bits<NB>(act, pending, a.R, roff, lg);
   }
+  if (OUT == OUT_PLAIN2) {  // two Linears of the SAME rows (the edge MLP's two node projections): one launch, one read of x
+    mfma_stage<NB>(acc, act, lds, slot, lane, true);
+    store_rows<NB, false>(acc, a.y, roff, lg);
+    mfma_stage<NB>(acc, act, lds, slot, lane, true);
+    store_rows<NB, false>(acc, a.y2, roff, lg);
+    continue;
+  }
   for (int l = 0; l < a.nstage; ++l) {
     mfma_stage<NB>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode, a.R);  // acc = bias + W act
     stamp();          // stage l done
@@ -631,7 +638,8 @@ template <int NB>
 int launch_fwd_n(int in_mode, int out_mode, const ChainFwdArgs& a, hipStream_t s) {
 #define BSMS_FWD(I, O) \
   if (in_mode == I && out_mode == O) return launch_fwd_t<NB, I, O>(a, s)
-  BSMS_FWD(IN_ROWS, OUT_PLAIN);   // node pre-projection x W^T
+  BSMS_FWD(IN_ROWS, OUT_PLAIN);   // x W^T
+  BSMS_FWD(IN_ROWS, OUT_PLAIN2);  // the two node pre-projections of the edge MLP
   BSMS_FWD(IN_ROWS2, OUT_PLAIN);  // its input gradient
   BSMS_FWD(IN_EDGE, OUT_LN);      // edge MLP
   BSMS_FWD(IN_ROWS2, OUT_LN);     // node MLP on [x, aggr]

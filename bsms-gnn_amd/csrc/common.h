@@ -45,7 +45,8 @@ struct SideLane {
   hipStream_t stream = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
 };
-int side_lane(SideLane** out);                       // for the current device
+constexpr int kSideLanes = 2;
+int side_lane(SideLane** out, int which = 0);        // for the current device; `which` < kSideLanes
 int side_fork(SideLane* lane, hipStream_t main);     // side waits for main
 int side_join(SideLane* lane, hipStream_t main);     // main waits for side
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

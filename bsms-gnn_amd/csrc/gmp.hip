@@ -174,11 +174,10 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
   // node pre-projections
   {
     ChainFwdArgs a{};
-    a.R = B * N; a.x = x; a.nstage = 1;
-    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wi); a.y = wk.Ps;   // bias b0 rides in the pack header
-    if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN, a, s))) return rc;
-    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wj); a.y = wk.Pd;
-    if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN, a, s))) return rc;
+    a.R = B * N; a.x = x; a.nstage = 2;   // both projections in one launch (OUT_PLAIN2); bias b0 rides in the first pack
+    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wi); a.y = wk.Ps;
+    a.wp[1] = reinterpret_cast<const float4*>(sv.e_wj); a.y2 = wk.Pd;
+    if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN2, a, s))) return rc;
   }
   // edge MLP + LayerNorm
   {
@@ -294,6 +293,16 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D);
     if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, ws))) return rc;
   }
+  // a second side stream takes the remaining weight gradients of the first edge Linear (fiber columns + bias now,
+  // the x-columns once dPs/dPd exist), so that the caller's stream only carries what grad_x depends on:
+  // gE[0] -> dPs, dPd -> grad_x
+  SideLane* lane2 = nullptr;
+  hipStream_t s2 = s;
+  const bool overlap2 = overlap && !(g_debug_flags & 32);
+  if (overlap2) {
+    if ((rc = side_lane(&lane2, 1)) || (rc = side_fork(lane2, s))) return rc;
+    s2 = lane2->stream;
+  }
   // gradient of the first edge Linear w.r.t. the two per-node projections
   if ((rc = rowsum_by_source(plan, wk.gE[0], B, D, wk.dPs, s))) return rc;
   if ((rc = rowsum_plan_order(plan, wk.gE[0], B, D, wk.dPd, s))) return rc;
@@ -305,9 +314,10 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p;
     a.out = ge[0]; a.os = 1; a.of = ldE0; a.colsum = ge[1];
     a.R = B * E; a.D = (int)D;
-    if ((rc = launch_small_wgrad(a, wk.sw, s))) return rc;
+    if ((rc = launch_small_wgrad(a, wk.sw, s2))) return rc;
   }
   // x-columns of W0_edge (the two projections)
+  if (overlap2 && (rc = side_fork(lane2, s))) return rc;   // lane 2 additionally waits for dPs / dPd
   {
     WgradJob jobs[2];
     auto set = [&](WgradJob& j, const float* G, int col0) {
@@ -315,7 +325,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     };
     set(jobs[0], wk.dPs, int(p + 1));
     set(jobs[1], wk.dPd, int(p + 1 + D));
-    if ((rc = launch_wgrad((int)D, jobs, 2, wk.wg2, s))) return rc;
+    if ((rc = launch_wgrad((int)D, jobs, 2, wk.wg2, s2))) return rc;
   }
   // grad_x += dPs Wi + dPd Wj
   {
@@ -327,6 +337,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_PLAIN, a, s))) return rc;
   }
   if (overlap && (rc = side_join(lane, s))) return rc;
+  if (overlap2 && (rc = side_join(lane2, s))) return rc;
   return BSMS_OK;
 }
 

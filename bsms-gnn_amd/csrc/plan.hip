@@ -21,14 +21,14 @@ void set_error(const char* fmt, ...) {
 
 namespace bsms {
 static std::mutex g_lane_mu;
-static SideLane g_lanes[64];
+static SideLane g_lanes[64][kSideLanes];
 
-int side_lane(SideLane** out) {
+int side_lane(SideLane** out, int which) {
   int dev = 0;
   BSMS_HIP_CHECK(hipGetDevice(&dev));
-  BSMS_REQUIRE(dev >= 0 && dev < 64, BSMS_E_UNSUPPORTED, "side_lane: device index %d", dev);
+  BSMS_REQUIRE(dev >= 0 && dev < 64 && which >= 0 && which < kSideLanes, BSMS_E_UNSUPPORTED, "side_lane: device %d lane %d", dev, which);
   std::lock_guard<std::mutex> lock(g_lane_mu);
-  SideLane& l = g_lanes[dev];
+  SideLane& l = g_lanes[dev][which];
   if (!l.stream) {
     BSMS_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.fork_ev, hipEventDisableTiming));
