@@ -248,6 +248,55 @@ def test_gmp_degenerate_rows(eng):
         assert rel_err(pm.grad.cpu(), pr.grad) < BWD_TOL, k
 
 
+@pytest.mark.parametrize("D,p,H", [(256, 3, 2), (64, 3, 3)])
+def test_gmp_other_widths(eng, D, p, H):
+    """Every latent width instantiates its own kernels (D = 256: 16 accumulator blocks, 155 KB of LDS per workgroup;
+    the surface config of BASELINE.json): forward, input and parameter gradients against the oracle."""
+    n, e = 210, 1500
+    g = random_graph(n, e, 4)
+    def build(seed):
+        torch.manual_seed(seed)
+        ref = ro.GMP(D, H, p)
+        x, pos = torch.randn(2, n, D, requires_grad=True), torch.rand(2, n, p)
+        return ref, (lambda: ref(x, g, pos)), x, pos
+
+    seed = pick_seed(lambda s: build(s)[:2], first=5)
+    ref, _, x, pos = build(seed)
+    mine = load_sd(eng.GMP(D, H, p), ref.state_dict())
+    y = ref(x, g, pos)
+    y.square().sum().backward()
+    xd = dev(x.detach()).requires_grad_(True)
+    yd = mine(xd, dev(g), dev(pos))
+    yd.square().sum().backward()
+    assert rel_err(yd.cpu(), y) < FWD_TOL and rel_err(xd.grad.cpu(), x.grad) < BWD_TOL
+    for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert rel_err(pm.grad.cpu(), pr.grad) < BWD_TOL, k
+
+
+def test_split_bf16_products_are_fp32_accurate(eng):
+    """The matrix cores multiply exact 3-way bf16 splits of the fp32 operands (chain.h).  Against an fp64 product
+    the engine's Linear must be at least as accurate as a plain fp32 matmul of the same data (not merely within
+    the 1e-5 parity tolerance): forward of one bias-free-equivalent layer stack and its weight gradient."""
+    torch.manual_seed(11)
+    R, D = 4096, 128
+    ref = ro.MLP(D, D, D, 1, True)
+    mine = load_sd(eng.MLP(D, D, D, 1, True), ref.state_dict())
+    x = torch.randn(R, D)
+    w0, b0 = ref.state_dict()["seq.0.weight"], ref.state_dict()["seq.0.bias"]
+    w1, b1 = ref.state_dict()["seq.2.weight"], ref.state_dict()["seq.2.bias"]
+    def stack(xx, dt):
+        h = torch.relu(xx.to(dt) @ w0.to(dt).T + b0.to(dt))
+        z = h @ w1.to(dt).T + b1.to(dt)
+        return torch.nn.functional.layer_norm(z, (D,))
+    y64 = stack(x, torch.float64)
+    y32 = stack(x, torch.float32)
+    yd = mine(dev(x)).cpu()
+    err_engine = float((yd.double() - y64).abs().max())
+    err_fp32 = float((y32.double() - y64).abs().max())
+    assert err_engine <= 2.0 * err_fp32 + 1e-7, (err_engine, err_fp32)
+    assert rel_err(yd, y64.float()) < 1e-6
+
+
 # ------------------------------------------------------------------------------------ A8,A9 BSGMP
 @pytest.mark.parametrize("tag,D,p", [("line11", 32, 3), ("del300", 32, 2), ("del64_d128", 128, 2)])
 def test_bsgmp_golden(eng, graphs, tag, D, p):
