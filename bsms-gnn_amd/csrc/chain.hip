@@ -217,20 +217,18 @@ __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
+// planes of K block kb2 (features 32 kb2 .. +31 of this lane's row)
 template <int NB>
-__device__ __forceinline__ void split_tile(const f32x4 (&act)[NB], u32x4 (&bh)[NB / 2], u32x4 (&bm)[NB / 2],
-                                           u32x4 (&bl)[NB / 2]) {
+__device__ __forceinline__ void split_block(const f32x4 (&act)[NB], int kb2, u32x4& bh, u32x4& bm, u32x4& bl) {
 #pragma unroll
-  for (int kb2 = 0; kb2 < NB / 2; ++kb2)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {  // dword v = slots 2v, 2v+1 = act[2 kb2 + (v >> 1)][2 (v & 1) + {0, 1}]
-      unsigned h0, m0, l0, h1, m1, l1;
-      split3(act[2 * kb2 + (v >> 1)][2 * (v & 1)], h0, m0, l0);
-      split3(act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1], h1, m1, l1);
-      bh[kb2][v] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-      bm[kb2][v] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-      bl[kb2][v] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
-    }
+  for (int v = 0; v < 4; ++v) {  // dword v = slots 2v, 2v+1 = act[2 kb2 + (v >> 1)][2 (v & 1) + {0, 1}]
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(act[2 * kb2 + (v >> 1)][2 * (v & 1)], h0, m0, l0);
+    split3(act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1], h1, m1, l1);
+    bh[v] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    bm[v] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    bl[v] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
+  }
 }
 
 __device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
@@ -242,18 +240,27 @@ __device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
 // header of the stage's first chunk instead of accumulating onto the caller's acc.
 // `store_base` (nullable, uniform) + `store_off`: HBM tensor / this lane's row offset that receives `act`; issued
 // right after the split so the store has the whole stage to drain.  All compute waves of the workgroup must call this together.
-template <int NB>
+template <int NB, bool TIMED = false>
 __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
                                            bool from_header, float* store_base = nullptr, int64_t store_off = -1,
-                                           int store_mode = 0, int64_t mask_rows = 0) {
+                                           int store_mode = 0, int64_t mask_rows = 0,
+                                           unsigned long long* waited = nullptr) {
   using R = Ring<NB>;
+  // The per-element VALU work of a stage (three-way split, sign bits) is spread over the chunks instead of sitting
+  // in front of the first MFMA: only K block 0 is split up front, block c + 1 is split in the shadow of chunk c's
+  // MFMAs (an MFMA occupies the issue port for 4 of its 16 cycles).
   u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
-  split_tile<NB>(act, bh, bm, bl);
+  split_block<NB>(act, 0, bh[0], bm[0], bl[0]);
   store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
-  if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);   // saved activation: + sign bits
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
-    lds_barrier();                                           // chunk has landed (and my reads of the last one are done)
+    if (TIMED) {   // experiments: cycles this wave spends waiting at the chunk barriers
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      lds_barrier();
+      *waited += __builtin_amdgcn_s_memtime() - t0;
+    } else {
+      lds_barrier();                                         // chunk has landed (and my reads of the last one are done)
+    }
     const float4* cur = lds + slot * R::CH4;
     if (++slot == R::NR) slot = 0;
     if (c == 0 && from_header) {
@@ -277,6 +284,10 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
         acc[t + 1] = mma(h1, bm[c], acc[t + 1]);
         acc[t] = mma(h0, bh[c], acc[t]);
         acc[t + 1] = mma(h1, bh[c], acc[t + 1]);
+      }
+      if (t == 0) {   // VALU work for later, placed among this chunk's MFMAs
+        if (c + 1 < R::NCH) split_block<NB>(act, c + 1, bh[c + 1], bm[c + 1], bl[c + 1]);
+        else if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);  // saved activation: + sign bits
       }
       {
         const float4 m0 = body[(t * 3 + 1) * 64], m1 = body[(t * 3 + 4) * 64];
@@ -358,6 +369,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
   const int64_t roff = live ? row * D : -1;  // row offset for stores; negative = no store
   int stamp_i = 0;
+  unsigned long long waited = 0;
   auto stamp = [&]() {  // experiments: wave 0 / lane 0 records the shader clock at phase boundaries
     if (TIMING && a.timing && tid == 0 && stamp_i < 16) a.timing[int64_t(tile) * 16 + stamp_i++] = __builtin_amdgcn_s_memtime();
   };
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     continue;
   }
   for (int l = 0; l < a.nstage; ++l) {
-    mfma_stage<NB>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode, a.R);  // acc = bias + W act
+    mfma_stage<NB, TIMING>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode, a.R, &waited);  // acc = bias + W act
     stamp();          // stage l done
     pending = nullptr;
     if (IN == IN_ROWS2 && l == 0) {
@@ -439,7 +451,10 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     }
   }
   stamp();
-  if (TIMING && a.timing && tid == 0) a.timing[int64_t(tile) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+  if (TIMING && a.timing && tid == 0) {
+    a.timing[int64_t(tile) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+    a.timing[int64_t(tile) * 16 + 11] = waited;
+  }
   if (!live) continue;
 
   // ---- output

@@ -42,6 +42,7 @@ for lvl in (0, 4):
     starts = np.sort(t[:, 0] - t[:, 0].min())
     print("  start times (ticks) of workgroup #0, #255, #1023, #2047, last:", [int(starts[min(i, len(starts) - 1)]) for i in (0, 255, 1023, 2047, len(starts) - 1)])
     print("  median tile life %.0f ticks; phases (median / p90):" % np.median(life))
+    print(f"    cycles waiting at the 12 chunk barriers (median / p90): {np.median(full[ok][:, 11]):9.0f} {np.percentile(full[ok][:, 11], 90):9.0f}")
     for k, nm in enumerate(names):
         print(f"    {nm:24s} {np.median(d[:, k]):9.0f} {np.percentile(d[:, k], 90):9.0f}")
 
