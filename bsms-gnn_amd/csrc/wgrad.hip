@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256) void k_small_wgrad(SmallWgradArgs a, float* pa
   float4 acc[NS + 1];
 #pragma unroll
   for (int s = 0; s <= NS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cs[SW_MAXS];   // column sums of the narrow matrix itself (decoder output bias), kept by the c4 == 0 lanes
+#pragma unroll
+  for (int s = 0; s < SW_MAXS; ++s) cs[s] = 0.f;
   const int64_t r0 = int64_t(blockIdx.x) * rows_per_wg, r1 = min(a.R, r0 + rows_per_wg);
   if (active) {
     for (int64_t r = r0 + rl; r < r1; r += nrl) {
@@ -355,9 +358,11 @@ __global__ __launch_bounds__(256) void k_small_wgrad(SmallWgradArgs a, float* pa
         acc[s].z = fmaf(g.z, sv[s], acc[s].z); acc[s].w = fmaf(g.w, sv[s], acc[s].w);
       }
       acc[NS].x += g.x; acc[NS].y += g.y; acc[NS].z += g.z; acc[NS].w += g.w;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) cs[s] += sv[s];
     }
   }
-  float* out = part + int64_t(blockIdx.x) * (SW_MAXS + 1) * D;
+  float* out = part + int64_t(blockIdx.x) * (SW_MAXS + 2) * D;
 #pragma unroll
   for (int s = 0; s <= NS; ++s) {  // combine the row lanes in fixed order
     red[tid] = active ? acc[s] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -372,6 +377,22 @@ __global__ __launch_bounds__(256) void k_small_wgrad(SmallWgradArgs a, float* pa
     }
     __syncthreads();
   }
+  if (a.colsum_S) {   // row SW_MAXS + 1 of the partial block: colsum of S in its first SW_MAXS entries
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      red[tid] = (active && c4 == 0) ? make_float4(cs[4 * h], cs[4 * h + 1], cs[4 * h + 2], cs[4 * h + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
+      if (tid == 0) {
+        float4 v = red[0];
+        for (int l = 1; l < nrl; ++l) {
+          const float4 w = red[l * d4];
+          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        *reinterpret_cast<float4*>(out + (SW_MAXS + 1) * D + 4 * h) = v;
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // one block per 8 output floats; 32 partial-lanes each sum every 32nd workgroup partial, fixed-order combine
@@ -380,33 +401,18 @@ __global__ __launch_bounds__(256) void k_small_reduce(SmallWgradArgs a, const fl
   const int D = a.D, S = a.S_cols;
   const int o = blockIdx.x * 8 + (threadIdx.x & 7), pl = threadIdx.x >> 3;
   const int s = o / D, f = o % D;
-  const bool valid = o < (SW_MAXS + 1) * D && (s < S || s == SW_MAXS);
+  // rows 0..S-1: narrow products; row SW_MAXS: colsum(G); row SW_MAXS+1, entries < S: colsum(S)
+  const bool valid = o < (SW_MAXS + 2) * D && (s < S || s == SW_MAXS || (s == SW_MAXS + 1 && f < S && a.colsum_S));
   float v = 0.f;
   if (valid)
-    for (int w = pl; w < nwg; w += 32) v += part[(int64_t(w) * (SW_MAXS + 1) + s) * D + f];
+    for (int w = pl; w < nwg; w += 32) v += part[(int64_t(w) * (SW_MAXS + 2) + s) * D + f];
   red[threadIdx.x] = v;
   __syncthreads();
   if (pl == 0 && valid) {
     for (int l = 1; l < 32; ++l) v += red[l * 8 + threadIdx.x];
     if (s < S) a.out[s * a.os + f * a.of] = v;
-    else if (a.colsum) a.colsum[f] = v;
-  }
-}
-
-// colsum of the narrow matrix itself (decoder output bias): tiny, one workgroup
-__global__ __launch_bounds__(256) void k_colsum_small(const float* S, int64_t R, int cols, float* out) {
-  __shared__ float red[256];
-  for (int c = 0; c < cols; ++c) {
-    float v = 0.f;
-    for (int64_t r = threadIdx.x; r < R; r += 256) v += S[r * cols + c];
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[c] = red[0];
-    __syncthreads();
+    else if (s == SW_MAXS) { if (a.colsum) a.colsum[f] = v; }
+    else a.colsum_S[f] = v;
   }
 }
 
@@ -466,7 +472,7 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   return BSMS_OK;
 }
 
-size_t small_wgrad_work_bytes(int D) { return size_t(SW_WGS) * (SW_MAXS + 1) * D * sizeof(float); }
+size_t small_wgrad_work_bytes(int D) { return size_t(SW_WGS) * (SW_MAXS + 2) * D * sizeof(float); }
 
 int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s) {
   BSMS_REQUIRE(a.S_cols >= 1 && a.S_cols <= SW_MAXS, BSMS_E_UNSUPPORTED, "small_wgrad: narrow width %d (max %d)", a.S_cols,
@@ -487,12 +493,9 @@ int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s) {
   }
 #undef BSMS_SW
   BSMS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)ceil_div((SW_MAXS + 1) * a.D, 8)), dim3(256), 0, s, a, (const float*)part, nwg);
+  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)ceil_div((SW_MAXS + 2) * a.D, 8)), dim3(256), 0, s, a, (const float*)part, nwg);
   BSMS_LAUNCH_CHECK();
-  if (a.colsum_S && a.S) {
-    hipLaunchKernelGGL(k_colsum_small, dim3(1), dim3(256), 0, s, a.S, a.R, a.S_cols, a.colsum_S);
-    BSMS_LAUNCH_CHECK();
-  }
+  BSMS_REQUIRE(!a.colsum_S || a.S, BSMS_E_INVALID_ARG, "small_wgrad: colsum_S needs an explicit narrow matrix");
   return BSMS_OK;
 }
 
