@@ -137,25 +137,6 @@ __device__ __forceinline__ float row_sum(const f32x4 (&v)[NB]) {
   return group_sum(s);
 }
 
-// ------------------------------------------------------------------------------- tile schedule
-// Persistent workgroups, XCD-aware: consecutive workgroup ids land on consecutive XCDs (8 of them, each with its own
-// L2), so workgroup w belongs to XCD w & 7.  Each XCD gets one CONTIGUOUS eighth of the tiles: edges are sorted by
-// target, so the Ps/Pd/dy rows a contiguous band of tiles gathers stay within that XCD's L2 instead of being spread
-// over all eight.  Within an XCD its gridDim/8 workgroups stride over the band.  Needs gridDim % 8 == 0 (the
-// launcher falls back to plain striding otherwise: XCDS = 1).
-struct TileSchedule {
-  int next, end, stride;
-  __device__ __forceinline__ TileSchedule(int ntiles) {
-    const int xcds = (gridDim.x % 8 == 0) ? 8 : 1;
-    const int per = (ntiles + xcds - 1) / xcds;            // tiles per XCD band
-    const int band = int(blockIdx.x) % xcds, local = int(blockIdx.x) / xcds;
-    stride = int(gridDim.x) / xcds;
-    next = band * per + local;
-    end = min(ntiles, (band + 1) * per);
-  }
-  __device__ __forceinline__ int count() const { return next < end ? (end - next + stride - 1) / stride : 0; }
-};
-
 // ---------------------------------------------------------------------------- weight streaming
 // Workgroup = 4 compute waves + 1 LOADER wave.  The loader streams the weight packs of all stages of every tile of
 // this workgroup, chunk by chunk (a chunk = 32 input features x all outputs x 3 bf16 planes + header, 25 KB at
@@ -210,7 +191,7 @@ __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, 
     for (int i = 0; i < R::SIDE_FLOATS / 256; ++i) glds16(reinterpret_cast<const float4*>(side) + i * 64 + lane, dst + i * 1024);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  const int my_tiles = TileSchedule(ntiles).count();
+  const int my_tiles = (ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
   const int per_tile = nseq * R::NCH, total = my_tiles * per_tile;
   int is = 0, ic = 0, islot = 0;                   // next chunk to issue: sequence entry, chunk in it, ring slot
   auto issue = [&]() {
@@ -382,8 +363,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   // Persistent workgroups: the grid is sized to what the chip holds at once and strides over the tiles, so a CU
   // never waits for the dispatcher to refill a slot (measured: 20-35 % of slot time was empty with one
   // workgroup per tile) and the loader is already fetching the next tile's first chunk during this epilogue.
-  const TileSchedule sched(a.ntiles);
-  for (int tile = sched.next; tile < sched.end; tile += sched.stride) {
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
   const int64_t row = int64_t(tile) * kTileRows + wave * 16 + (lane & 15);
   const bool live = row < a.R;
   const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
@@ -541,8 +521,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     return;
   }
   int slot = 0;  // ring slot of the next chunk, across this workgroup's tiles
-  const TileSchedule sched(a.ntiles);
-  for (int tile = sched.next; tile < sched.end; tile += sched.stride) {  // persistent workgroups (see k_chain_fwd)
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {  // persistent workgroups (see k_chain_fwd)
   const int64_t row = int64_t(tile) * kTileRows + wave * 16 + (lane & 15);
   const bool live = row < a.R;
   const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
@@ -638,9 +617,7 @@ unsigned persistent_grid(int64_t ntiles) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  int64_t g = std::min<int64_t>(ntiles, int64_t(cus) * resident_per_cu<NB>());
-  if (g >= 8) g = (g + 7) / 8 * 8;   // whole rounds of the 8 XCDs (TileSchedule); surplus workgroups find no tile
-  return (unsigned)g;
+  return (unsigned)std::min<int64_t>(ntiles, int64_t(cus) * resident_per_cu<NB>());
 }
 
 template <int NB, int IN, int OUT>
