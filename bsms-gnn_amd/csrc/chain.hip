@@ -96,6 +96,38 @@ __device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* base, in
   }
 }
 
+// Non-temporal (streaming) stores of a saved tensor, in 128-byte pieces.  In the chain layout one store instruction
+// writes, per row, the 64 bytes held by that row's four lanes; streaming stores of 64-byte pieces run at 3.1 TB/s,
+// of 128-byte pieces at 5.3 TB/s (profiles/census/store_bw.hip).  So feature blocks t, t+1 are paired: the lower
+// eight rows of the wave keep block t and fetch their partner lane's (row + 8) block t+1 with one DPP half-row
+// rotation; instruction A then writes rows 0-7 (both blocks = 128 contiguous bytes per row), instruction B rows 8-15.
+// `row` is this lane's own row (may be >= nrows: the lane still carries its partner's data).
+template <int NB>
+__device__ __forceinline__ void store_rows_stream(const f32x4 (&v)[NB], float* base, int64_t row, int64_t nrows, int lane) {
+  if (!base) return;
+  constexpr int D = NB * 16;
+  const int g = lane >> 4;
+  const bool hi = (lane & 8) != 0;
+  const int64_t rowA = row - (lane & 8), rowB = rowA + 8;
+  float* pA = base + rowA * D + 4 * g + (hi ? 16 : 0);
+  float* pB = base + rowB * D + 4 * g + (hi ? 0 : 16);
+  const bool liveA = rowA < nrows, liveB = rowB < nrows;
+#pragma unroll
+  for (int t = 0; t < NB; t += 2) {
+    using i32x4 = __attribute__((ext_vector_type(4))) int;
+    const i32x4 own = __builtin_bit_cast(i32x4, v[t + 1]);
+    i32x4 got;   // partner's block t + 1 (row_ror:8 = swap the two halves of a 16-lane row)
+    got[0] = __builtin_amdgcn_update_dpp(own[0], own[0], 0x128, 0xf, 0xf, false);
+    got[1] = __builtin_amdgcn_update_dpp(own[1], own[1], 0x128, 0xf, 0xf, false);
+    got[2] = __builtin_amdgcn_update_dpp(own[2], own[2], 0x128, 0xf, 0xf, false);
+    got[3] = __builtin_amdgcn_update_dpp(own[3], own[3], 0x128, 0xf, 0xf, false);
+    const f32x4 x = __builtin_bit_cast(f32x4, got);
+    const f32x4 dA = hi ? x : v[t], dB = hi ? v[t] : x;
+    if (liveA) __builtin_nontemporal_store(dA, reinterpret_cast<f32x4*>(pA + 16 * t));
+    if (liveB) __builtin_nontemporal_store(dB, reinterpret_cast<f32x4*>(pB + 16 * t));
+  }
+}
+
 // ReLU sign bits of this lane's 4 NB values: bit (4 t + r) of word (4 t + r) / 32
 template <int NB>
 constexpr int mask_words() { return NB <= 8 ? 1 : NB / 8; }
@@ -244,14 +276,15 @@ template <int NB, bool TIMED = false>
 __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
                                            bool from_header, float* store_base = nullptr, int64_t store_off = -1,
                                            int store_mode = 0, int64_t mask_rows = 0,
-                                           unsigned long long* waited = nullptr) {
+                                           unsigned long long* waited = nullptr, int64_t row = 0, int64_t nrows = 0) {
   using R = Ring<NB>;
   // The per-element VALU work of a stage (three-way split, sign bits) is spread over the chunks instead of sitting
   // in front of the first MFMA: only K block 0 is split up front, block c + 1 is split in the shadow of chunk c's
   // MFMAs (an MFMA occupies the issue port for 4 of its 16 cycles).
   u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
   split_block<NB>(act, 0, bh[0], bm[0], bl[0]);
-  store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
+  if (store_mode == 1 && nrows > 0) store_rows_stream<NB>(act, store_base, row, nrows, lane);   // saved tensors: streaming stores
+  else store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     if (TIMED) {   // experiments: cycles this wave spends waiting at the chunk barriers
@@ -436,7 +469,8 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     continue;
   }
   for (int l = 0; l < a.nstage; ++l) {
-    mfma_stage<NB, TIMING>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode, a.R, &waited);  // acc = bias + W act
+    mfma_stage<NB, TIMING>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode & 3, (a.store_mode & 4) ? 0 : a.R, &waited,
+                           row, (a.store_mode & 8) ? 0 : a.R);  // acc = bias + W act
     stamp();          // stage l done
     pending = nullptr;
     if (IN == IN_ROWS2 && l == 0) {
@@ -570,7 +604,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
       mbits[w] = a.mask[k] ? reinterpret_cast<const unsigned*>(a.mask[k] + a.R * D)[rowc * (4 * mask_words<NB>()) + lg * mask_words<NB>() + w]
                            : 0xffffffffu;
     zero_tile<NB>(acc);
-    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode);
+    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode & 3, 0, nullptr, row, (a.store_mode & 8) ? 0 : a.R);
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll

@@ -192,7 +192,7 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
     }
     a.y = sv.e_y; a.rstd = sv.e_rstd;
     a.timing = g_timing;
-    a.store_mode = (g_debug_flags & 2) ? 0 : 1;   // saved activations are streamed with non-temporal stores
+    a.store_mode = ((g_debug_flags & 2) ? 0 : 1) | ((g_debug_flags & 64) ? 4 : 0) | ((g_debug_flags & 128) ? 8 : 0);   // non-temporal stores (experiments: +4 no sign bits, +8 unpaired 64-byte pieces)
     a.out_mode = (g_debug_flags & 4) ? 1 : 0;
     if (g_debug_flags & 1) {
       a.store_in = nullptr;
@@ -255,7 +255,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
   // edge MLP backward (gradient of the aggregation = gather by target)
   {
     ChainBwdArgs a{};
-    a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd; a.store_mode = (g_debug_flags & 2) ? 0 : 1;
+    a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd; a.store_mode = ((g_debug_flags & 2) ? 0 : 1) | ((g_debug_flags & 128) ? 8 : 0);
     a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
     a.nstage = H;
     a.gstore[0] = wk.gE[H];
