@@ -103,7 +103,8 @@ __device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* base, in
 // rotation; instruction A then writes rows 0-7 (both blocks = 128 contiguous bytes per row), instruction B rows 8-15.
 // `row` is this lane's own row (may be >= nrows: the lane still carries its partner's data).
 template <int NB>
-__device__ __forceinline__ void store_rows_stream(const f32x4 (&v)[NB], float* base, int64_t row, int64_t nrows, int lane) {
+__device__ __forceinline__ void store_rows_stream(const f32x4 (&v)[NB], float* base, int64_t row, int64_t nrows, int lane,
+                                                  bool streaming = true) {
   if (!base) return;
   constexpr int D = NB * 16;
   const int g = lane >> 4;
@@ -123,8 +124,13 @@ __device__ __forceinline__ void store_rows_stream(const f32x4 (&v)[NB], float* b
     got[3] = __builtin_amdgcn_update_dpp(own[3], own[3], 0x128, 0xf, 0xf, false);
     const f32x4 x = __builtin_bit_cast(f32x4, got);
     const f32x4 dA = hi ? x : v[t], dB = hi ? v[t] : x;
-    if (liveA) __builtin_nontemporal_store(dA, reinterpret_cast<f32x4*>(pA + 16 * t));
-    if (liveB) __builtin_nontemporal_store(dB, reinterpret_cast<f32x4*>(pB + 16 * t));
+    if (streaming) {
+      if (liveA) __builtin_nontemporal_store(dA, reinterpret_cast<f32x4*>(pA + 16 * t));
+      if (liveB) __builtin_nontemporal_store(dB, reinterpret_cast<f32x4*>(pB + 16 * t));
+    } else {   // same 128-byte pieces, but allowed to stay in L2 / the memory-side cache for a reader that follows soon
+      if (liveA) *reinterpret_cast<f32x4*>(pA + 16 * t) = dA;
+      if (liveB) *reinterpret_cast<f32x4*>(pB + 16 * t) = dB;
+    }
   }
 }
 
@@ -283,7 +289,7 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
   // MFMAs (an MFMA occupies the issue port for 4 of its 16 cycles).
   u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
   split_block<NB>(act, 0, bh[0], bm[0], bl[0]);
-  if (store_mode == 1 && nrows > 0) store_rows_stream<NB>(act, store_base, row, nrows, lane);   // saved tensors: streaming stores
+  if ((store_mode == 1 || store_mode == 2) && nrows > 0) store_rows_stream<NB>(act, store_base, row, nrows, lane, store_mode == 1);   // saved tensors
   else store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {

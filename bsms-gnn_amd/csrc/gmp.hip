@@ -255,7 +255,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
   // edge MLP backward (gradient of the aggregation = gather by target)
   {
     ChainBwdArgs a{};
-    a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd; a.store_mode = ((g_debug_flags & 2) ? 0 : 1) | ((g_debug_flags & 128) ? 8 : 0);
+    a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd; a.store_mode = ((g_debug_flags & 2) ? 0 : (g_debug_flags & 256) ? 2 : 1) | ((g_debug_flags & 128) ? 8 : 0);
     a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
     a.nstage = H;
     a.gstore[0] = wk.gE[H];

@@ -90,6 +90,8 @@ constexpr int WG_THREADS = 1024;  // 16 waves = 4 per SIMD, one workgroup per CU
 constexpr int NPF = 3;            // chunks in flight in registers beyond the one being staged
 static_assert(NPF == 3, "the step schedule in k_wgrad is written out for three register sets");
 
+// TIMING: experiments (profiles/wgrad_timeline.py); the production instantiation carries no stamps
+template <bool TIMING>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   extern __shared__ __attribute__((aligned(16))) short planes[];  // [2 buffers][G|A][hi|mid|lo][32 rows][LROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   };
   int stamp_i = 0;
   auto stamp = [&]() {  // experiments: waves 0 and 4 record the shader clock (64 slots each)
-    if (tab.timing && (tid == 0 || tid == 256) && stamp_i < 64)
+    if (TIMING && tab.timing && (tid == 0 || tid == 256) && stamp_i < 64)
       tab.timing[(int64_t(blockIdx.x) * 2 + (tid >> 8)) * 64 + stamp_i++] = __builtin_amdgcn_s_memtime();
   };
   auto step = [&](int c, auto set1_tag, auto buf_tag) {
@@ -462,10 +464,13 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   tab.colsums = tab.partials + size_t(kMaxTiles) * TB * TB;
   tab.timing = g_wgrad_timing;
   const size_t lds = size_t(2) * 6 * PLANE * sizeof(short);   // 108 KB: 2 x [G|A][3 planes][32 rows][288 B]
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS", lds);
-  hipLaunchKernelGGL(k_wgrad, dim3(first), dim3(WG_THREADS), lds, s, tab);
+  static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  BSMS_REQUIRE(attr == hipSuccess && attr_t == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS", lds);
+  if (tab.timing) hipLaunchKernelGGL(k_wgrad<true>, dim3(first), dim3(WG_THREADS), lds, s, tab);
+  else hipLaunchKernelGGL(k_wgrad<false>, dim3(first), dim3(WG_THREADS), lds, s, tab);
   BSMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div((D * D + D) / 4, 64), njobs), dim3(256), 0, s, tab);
   BSMS_LAUNCH_CHECK();

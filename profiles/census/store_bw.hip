@@ -25,6 +25,35 @@ __global__ __launch_bounds__(256) void k_store(float* out, long rows) {
     }
   }
 }
+template <int PATTERN>
+__global__ __launch_bounds__(256) void k_load(const float* in, float* sink, long rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (long tile = blockIdx.x; tile * 64 < rows; tile += gridDim.x) {
+    const long row0 = tile * 64 + wave * 16;
+    f32x4 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4* p;
+      if (PATTERN == 0) p = reinterpret_cast<const f32x4*>(in + row0 * 128 + t * 256 + lane * 4);
+      else if (PATTERN == 1) p = reinterpret_cast<const f32x4*>(in + (row0 + (lane & 15)) * 128 + 16 * t + 4 * (lane >> 4));
+      else p = reinterpret_cast<const f32x4*>(in + (row0 + 8 * (t & 1) + (lane & 7)) * 128 + 32 * (t >> 1) + 4 * (lane >> 3));
+      v[t] = *p;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc += v[t];
+  }
+  if (acc[0] == 12345.678f) sink[threadIdx.x] = acc[1] + acc[2] + acc[3];
+}
+template <int P> void runl(float* d, long rows, const char* name) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_load<P>), dim3(2048), dim3(256), 0, 0, d, d, rows);
+  hipEventRecord(a);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_load<P>), dim3(2048), dim3(256), 0, 0, d, d, rows);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  printf("%-40s %7.1f us per 512 MB  = %.2f TB/s\n", name, ms * 100, rows * 512.0 * 10 / (ms * 1e-3) / 1e12);
+}
 template <int P, bool NT> void run(float* d, long rows, const char* name) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_store<P, NT>), dim3(2048), dim3(256), 0, 0, d, rows);
@@ -45,5 +74,8 @@ int main() {
   run<2, true>(d, rows, "8 rows x 128 B pieces, nt");
   run<3, false>(d, rows, "4 rows x 256 B pieces, plain");
   run<3, true>(d, rows, "4 rows x 256 B pieces, nt");
+  runl<0>(d, rows, "LOAD lane-linear");
+  runl<1>(d, rows, "LOAD chain layout (64 B pieces)");
+  runl<2>(d, rows, "LOAD 8 rows x 128 B pieces");
   return 0;
 }
