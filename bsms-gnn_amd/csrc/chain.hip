@@ -101,36 +101,34 @@ __device__ __forceinline__ void store_rows(const f32x4 (&v)[NB], float* base, in
 // of 128-byte pieces at 5.3 TB/s (profiles/census/store_bw.hip).  So feature blocks t, t+1 are paired: the lower
 // eight rows of the wave keep block t and fetch their partner lane's (row + 8) block t+1 with one DPP half-row
 // rotation; instruction A then writes rows 0-7 (both blocks = 128 contiguous bytes per row), instruction B rows 8-15.
-// `row` is this lane's own row (may be >= nrows: the lane still carries its partner's data).
+// `row` is this lane's own row (may be >= nrows: the lane still carries its partner's data).  One pair per call: the
+// chain issues pair c inside chunk c of the stage, because eight stores at once fill the CU's store path (its share
+// of the chip's write bandwidth is ~10 B/clk) and the in-order wave then sits on the next store instead of its MFMAs.
 template <int NB>
-__device__ __forceinline__ void store_rows_stream(const f32x4 (&v)[NB], float* base, int64_t row, int64_t nrows, int lane,
-                                                  bool streaming = true) {
+__device__ __forceinline__ void store_pair_stream(const f32x4 (&v)[NB], float* base, int64_t row, int64_t nrows, int lane,
+                                                  int t, bool streaming = true) {   // feature blocks t, t + 1 (t even)
   if (!base) return;
   constexpr int D = NB * 16;
   const int g = lane >> 4;
   const bool hi = (lane & 8) != 0;
   const int64_t rowA = row - (lane & 8), rowB = rowA + 8;
-  float* pA = base + rowA * D + 4 * g + (hi ? 16 : 0);
-  float* pB = base + rowB * D + 4 * g + (hi ? 0 : 16);
-  const bool liveA = rowA < nrows, liveB = rowB < nrows;
-#pragma unroll
-  for (int t = 0; t < NB; t += 2) {
-    using i32x4 = __attribute__((ext_vector_type(4))) int;
-    const i32x4 own = __builtin_bit_cast(i32x4, v[t + 1]);
-    i32x4 got;   // partner's block t + 1 (row_ror:8 = swap the two halves of a 16-lane row)
-    got[0] = __builtin_amdgcn_update_dpp(own[0], own[0], 0x128, 0xf, 0xf, false);
-    got[1] = __builtin_amdgcn_update_dpp(own[1], own[1], 0x128, 0xf, 0xf, false);
-    got[2] = __builtin_amdgcn_update_dpp(own[2], own[2], 0x128, 0xf, 0xf, false);
-    got[3] = __builtin_amdgcn_update_dpp(own[3], own[3], 0x128, 0xf, 0xf, false);
-    const f32x4 x = __builtin_bit_cast(f32x4, got);
-    const f32x4 dA = hi ? x : v[t], dB = hi ? v[t] : x;
-    if (streaming) {
-      if (liveA) __builtin_nontemporal_store(dA, reinterpret_cast<f32x4*>(pA + 16 * t));
-      if (liveB) __builtin_nontemporal_store(dB, reinterpret_cast<f32x4*>(pB + 16 * t));
-    } else {   // same 128-byte pieces, but allowed to stay in L2 / the memory-side cache for a reader that follows soon
-      if (liveA) *reinterpret_cast<f32x4*>(pA + 16 * t) = dA;
-      if (liveB) *reinterpret_cast<f32x4*>(pB + 16 * t) = dB;
-    }
+  float* pA = base + rowA * D + 4 * g + (hi ? 16 : 0) + 16 * t;
+  float* pB = base + rowB * D + 4 * g + (hi ? 0 : 16) + 16 * t;
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  const i32x4 own = __builtin_bit_cast(i32x4, v[t + 1]);
+  i32x4 got;   // partner's block t + 1 (row_ror:8 = swap the two halves of a 16-lane row)
+  got[0] = __builtin_amdgcn_update_dpp(own[0], own[0], 0x128, 0xf, 0xf, false);
+  got[1] = __builtin_amdgcn_update_dpp(own[1], own[1], 0x128, 0xf, 0xf, false);
+  got[2] = __builtin_amdgcn_update_dpp(own[2], own[2], 0x128, 0xf, 0xf, false);
+  got[3] = __builtin_amdgcn_update_dpp(own[3], own[3], 0x128, 0xf, 0xf, false);
+  const f32x4 x = __builtin_bit_cast(f32x4, got);
+  const f32x4 dA = hi ? x : v[t], dB = hi ? v[t] : x;
+  if (streaming) {
+    if (rowA < nrows) __builtin_nontemporal_store(dA, reinterpret_cast<f32x4*>(pA));
+    if (rowB < nrows) __builtin_nontemporal_store(dB, reinterpret_cast<f32x4*>(pB));
+  } else {   // same 128-byte pieces, but allowed to stay in L2 / the memory-side cache for a reader that follows soon
+    if (rowA < nrows) *reinterpret_cast<f32x4*>(pA) = dA;
+    if (rowB < nrows) *reinterpret_cast<f32x4*>(pB) = dB;
   }
 }
 
@@ -289,8 +287,8 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
   // MFMAs (an MFMA occupies the issue port for 4 of its 16 cycles).
   u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
   split_block<NB>(act, 0, bh[0], bm[0], bl[0]);
-  if ((store_mode == 1 || store_mode == 2) && nrows > 0) store_rows_stream<NB>(act, store_base, row, nrows, lane, store_mode == 1);   // saved tensors
-  else store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
+  const bool paired = (store_mode == 1 || store_mode == 2) && nrows > 0;   // saved tensors: 128-byte pieces, one pair per chunk
+  if (!paired) store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     if (TIMED) {   // experiments: cycles this wave spends waiting at the chunk barriers
@@ -310,6 +308,7 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
         acc[t] = f32x4{x.x, x.y, x.z, x.w};
       }
     }
+    if (paired) store_pair_stream<NB>(act, store_base, row, nrows, lane, 2 * c, store_mode == 1);
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
     // two accumulators interleaved so that back-to-back MFMAs are independent; one weight plane at a time (each
     // fragment pair is dead after its products: 8 fragment registers live + the next pair in flight)
