@@ -442,8 +442,12 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   const int blocks = tab.nblk * tab.nblk;
   int64_t total_rows = 0;
   for (int j = 0; j < njobs; ++j) total_rows += jobs[j].R;
-  // aim for ~512 workgroups (two per CU, one resident at a time) over all jobs; slabs are multiples of RC rows, at least 128
-  int64_t rows_per = std::max<int64_t>(128, ceil_div(total_rows * blocks, 512));
+  // Slab length: aim for ~128 workgroups over all jobs = half the CUs (one workgroup per CU is resident).  Measured
+  // (same-box A/B, steps/s of the training step): 64 -> 110.7, 96 -> 125.5, 128 -> 131.0, 160 -> 124.8, 192 -> 126.4,
+  // 256 -> 130.5, 512 -> 128.0, 768 -> 126.5: long slabs amortise the pipeline fill and the partial-block traffic, a
+  // grid that spills into a second, nearly empty round loses, and half the chip is left to the kernels that run
+  // concurrently on the caller's stream.  Slabs are multiples of 6 chunks, at least 128 rows.
+  int64_t rows_per = std::max<int64_t>(128, ceil_div(total_rows * blocks, 128));
   rows_per = ceil_div(rows_per, 6 * RC) * (6 * RC);   // whole groups of six chunks (k_wgrad's step schedule)
   for (;;) {
     int64_t tiles = 0;
