@@ -6,9 +6,10 @@ import torch
 import bsms_gnn_amd as eng
 from bench import build_workload
 wl = build_workload("airfoil", 8, "cuda")
-B, D, K = 8, 128, 20
+B, D = 8, 128
 tot_f = tot_b = 0.0
 for lvl, (n, e) in enumerate(wl["levels"]):
+    K = 4 if lvl == 0 else 20   # K saved-for-backward sets are alive at once (1.2 GB each at L0)
     g = wl["m_gs"][lvl][0]
     plan = eng.plan_for(g, n)
     gmp = eng.GMP(D, 3, 2).cuda()
