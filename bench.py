@@ -292,7 +292,7 @@ def main():
     if rank == 0:
         n_params = sum(p.numel() for p in sim.parameters() if p.requires_grad)
         line = {
-            "metric": "rollout steps/sec (1-step fwd+bwd) on airfoil mesh, batch=8",
+            "metric": f"rollout steps/sec (1-step fwd+bwd) on {args.workload} mesh, batch={args.batch}",
             "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -40,6 +40,12 @@ SIGNATURES = {
                              c_void_p, c_void_p]),
     "bsms_gmp_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
                              c_void_p, c_void_p, PP, c_void_p]),
+    "bsms_bsgmp_saved_bytes": (c_size_t, [PP, c_int, c_i64, c_i64, c_i64, c_int]),
+    "bsms_bsgmp_work_bytes": (c_size_t, [PP, c_int, c_i64, c_i64, c_i64, c_int]),
+    "bsms_bsgmp_fwd": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    "bsms_bsgmp_bwd": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
+                               c_void_p, c_void_p, PP, c_void_p]),
     "bsms_hierarchy_create": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, PP]),
     "bsms_hierarchy_destroy": (c_int, [c_void_p]),
     "bsms_hierarchy_level_nodes": (c_i64, [c_void_p, c_int]),

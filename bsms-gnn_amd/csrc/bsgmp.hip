@@ -1,0 +1,225 @@
+// BSGMP: the whole bi-stride U-Net of GMP blocks in ONE library call (ops/BSMS.py:39-104).
+//
+//   down  i = 0..L-1 :  s_i = GMP_down[i](h_i, pos_i) ;  h_{i+1} = restrict_i(s_i) ;  pos_{i+1} = restrict_i(pos_i)
+//   bottom           :  h   = GMP_bottom(h_L, pos_L)
+//   up    i = 0..L-1 :  d = L-1-i ;  u_d = prolong_d(h) ;  h = GMP_up[i](u_d, pos_d) + s_d
+//
+// restrict = WeightedEdgeConv + index by m_ids fused, prolong = Unpool + WeightedEdgeConv(aggragating=False) fused
+// (bsms_edge_conv with `pooled`).  The entry only sequences the block / transition entries of this library on the
+// caller's stream -- no new arithmetic -- so that a training step costs the host two calls instead of ~60 autograd
+// nodes (the Python mirror of the reference's module tree needed 5.4 ms per step to enqueue what the GPU runs in
+// 7.6 ms at airfoil size and was the limit outright at cylinder size).
+#include "common.h"
+
+using namespace bsms;
+
+namespace {
+
+constexpr int kMaxLevels = 16;
+
+struct Shape {
+  int L;
+  int64_t B, D, p, N[kMaxLevels + 1], E[kMaxLevels + 1];
+  int H;
+};
+
+struct Carve {
+  char* base;
+  size_t off = 0;
+  explicit Carve(void* b) : base(reinterpret_cast<char*>(b)) {}
+  char* bytes(size_t n) {
+    char* r = base ? base + off : nullptr;
+    off += align_up(n);
+    return r;
+  }
+  float* floats(size_t n) { return reinterpret_cast<float*>(bytes(n * sizeof(float))); }
+};
+
+// what the backward needs: every block's own saved blob, the inputs of the blocks (x of a GMP is needed by its
+// backward) and the coarse positions
+struct Saved {
+  void* gmp[2 * kMaxLevels + 1];   // down 0..L-1, bottom, up 0..L-1
+  float* hin[kMaxLevels + 1];      // input of GMP_down[i] for i >= 1 and of the bottom block (hin[0] = caller's h)
+  float* pos[kMaxLevels + 1];      // positions of level i >= 1 (pos[0] = caller's)
+  float* upin[kMaxLevels];         // input of the up block acting on level d
+  size_t bytes;
+};
+Saved carve_saved(void* base, const Shape& s, bool training) {
+  Carve c(base);
+  Saved v{};
+  for (int i = 0; i < s.L; ++i) v.gmp[i] = training ? c.bytes(bsms_gmp_saved_bytes(s.B, s.N[i], s.E[i], s.D, s.H)) : nullptr;
+  v.gmp[s.L] = training ? c.bytes(bsms_gmp_saved_bytes(s.B, s.N[s.L], s.E[s.L], s.D, s.H)) : nullptr;
+  for (int i = 0; i < s.L; ++i) {
+    const int d = s.L - 1 - i;
+    v.gmp[s.L + 1 + i] = training ? c.bytes(bsms_gmp_saved_bytes(s.B, s.N[d], s.E[d], s.D, s.H)) : nullptr;
+  }
+  for (int i = 1; i <= s.L; ++i) {
+    v.hin[i] = c.floats(size_t(s.B) * s.N[i] * s.D);
+    v.pos[i] = c.floats(size_t(s.B) * s.N[i] * s.p);
+  }
+  for (int d = 0; d < s.L; ++d) v.upin[d] = c.floats(size_t(s.B) * s.N[d] * s.D);
+  v.bytes = c.off;
+  return v;
+}
+
+struct Work {
+  void* gmp;                      // scratch of one block call (largest level)
+  float* skip[kMaxLevels];        // fwd: outputs of the down blocks; bwd: gradient arriving at the skip connections
+  float* a[2];                    // two ping-pong level-0 sized buffers
+  size_t bytes;
+};
+Work carve_work(void* base, const Shape& s) {
+  Carve c(base);
+  Work w{};
+  size_t g = 0;
+  for (int i = 0; i <= s.L; ++i) g = std::max(g, bsms_gmp_work_bytes(s.B, s.N[i], s.E[i], s.D, s.H));
+  w.gmp = c.bytes(g);
+  for (int i = 0; i < s.L; ++i) w.skip[i] = c.floats(size_t(s.B) * s.N[i] * s.D);
+  for (int k = 0; k < 2; ++k) w.a[k] = c.floats(size_t(s.B) * s.N[0] * s.D);
+  w.bytes = c.off;
+  return w;
+}
+
+int make_shape(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int H, Shape* s, const char* who) {
+  BSMS_REQUIRE(plans != nullptr && L >= 0 && L <= kMaxLevels, BSMS_E_INVALID_ARG, "%s: unet_depth %d (0..%d)", who, L, kMaxLevels);
+  s->L = L; s->B = B; s->D = D; s->p = p; s->H = H;
+  for (int i = 0; i <= L; ++i) {
+    BSMS_REQUIRE(plans[i] != nullptr, BSMS_E_INVALID_ARG, "%s: plan of level %d is null", who, i);
+    s->N[i] = plans[i]->N;
+    s->E[i] = plans[i]->E;
+    if (i > 0)
+      BSMS_REQUIRE(plans[i - 1]->Nk == s->N[i], BSMS_E_SHAPE, "%s: level %d keeps %lld nodes but level %d has %lld", who, i - 1,
+                   (long long)plans[i - 1]->Nk, i, (long long)s->N[i]);
+  }
+  return BSMS_OK;
+}
+
+__global__ __launch_bounds__(256) void k_add_rows(const float4* a, const float4* b, float4* out, int64_t n4) {
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += int64_t(gridDim.x) * 256) {
+    const float4 x = a[i], y = b[i];
+    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+int add_rows(const float* a, const float* b, float* out, int64_t n, hipStream_t s) {  // n % 4 == 0 (D is a multiple of 32)
+  if (n == 0) return BSMS_OK;
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(k_add_rows, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n4);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
+
+// parameters of block k: 4 (H + 1) pointers (mlp_node then mlp_edge), blocks ordered down 0..L-1, bottom, up 0..L-1
+inline const float* const* block(const float* const* params, int k, int H) { return params + size_t(k) * 4 * (H + 1); }
+inline float* const* block(float* const* grads, int k, int H) { return grads + size_t(k) * 4 * (H + 1); }
+
+}  // namespace
+
+extern "C" size_t bsms_bsgmp_saved_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden) {
+  Shape s;
+  if (make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_saved_bytes")) return 0;
+  return carve_saved(nullptr, s, true).bytes;
+}
+extern "C" size_t bsms_bsgmp_work_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden) {
+  Shape s;
+  if (make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_work_bytes")) return 0;
+  // inference keeps the level inputs in the scratch as well
+  return carve_work(nullptr, s).bytes + carve_saved(nullptr, s, false).bytes;
+}
+
+extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                              int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                              const float* const* params, float* out, void* saved, void* work, bsms_stream_t stream) {
+  Shape s;
+  int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_fwd");
+  if (rc) return rc;
+  BSMS_REQUIRE(h && pos && params && out && work && (ew || L == 0), BSMS_E_INVALID_ARG, "bsgmp_fwd: null argument");
+  hipStream_t st = as_stream(stream);
+  const bool training = saved != nullptr;
+  Work w = carve_work(work, s);
+  Saved v = training ? carve_saved(saved, s, true) : carve_saved(reinterpret_cast<char*>(work) + w.bytes, s, false);
+  const int64_t posB = pos_batch_stride ? B : 1;   // a 2-D pos is shared by the batch (ops/basic.py:87-88)
+
+  const float* hi = h;
+  const float* pi = pos;
+  int64_t pstride = pos_batch_stride;
+  const float* pos_l[kMaxLevels + 1];
+  int64_t pstride_l[kMaxLevels + 1];
+  for (int i = 0; i < L; ++i) {
+    pos_l[i] = pi; pstride_l[i] = pstride;
+    if ((rc = bsms_gmp_fwd(plans[i], hi, pi, B, D, p, pstride, hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp, stream))) return rc;
+    // restrict features and positions to the kept nodes (ops/BSMS.py:74-75, 79-88)
+    if ((rc = bsms_edge_conv(plans[i], w.skip[i], B, D, ew[i], 1, 1, v.hin[i + 1], stream))) return rc;
+    if ((rc = bsms_edge_conv(plans[i], pi, posB, p, ew[i], 1, 1, v.pos[i + 1], stream))) return rc;
+    hi = v.hin[i + 1];
+    pi = v.pos[i + 1];
+    pstride = pos_batch_stride ? s.N[i + 1] * p : 0;
+  }
+  pos_l[L] = pi; pstride_l[L] = pstride;
+  float* cur = (L == 0) ? out : w.a[0];
+  if ((rc = bsms_gmp_fwd(plans[L], hi, pi, B, D, p, pstride, hidden, block(params, L, hidden), cur, v.gmp[L], w.gmp, stream))) return rc;
+  for (int i = 0; i < L; ++i) {
+    const int d = L - 1 - i;
+    if ((rc = bsms_edge_conv(plans[d], cur, B, D, ew[d], 0, 1, v.upin[d], stream))) return rc;   // prolong (BSMS.py:98-100)
+    float* tmp = w.a[(i + 1) & 1];
+    if ((rc = bsms_gmp_fwd(plans[d], v.upin[d], pos_l[d], B, D, p, pstride_l[d], hidden, block(params, L + 1 + i, hidden), tmp,
+                           v.gmp[L + 1 + i], w.gmp, stream))) return rc;
+    float* nxt = (d == 0) ? out : w.a[i & 1];
+    if ((rc = add_rows(tmp, w.skip[d], nxt, B * s.N[d] * D, st))) return rc;                      // skip connection (BSMS.py:102)
+    cur = nxt;
+  }
+  return BSMS_OK;
+}
+
+extern "C" int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                              const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                              const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
+                              bsms_stream_t stream) {
+  Shape s;
+  int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_bwd");
+  if (rc) return rc;
+  BSMS_REQUIRE(h && pos && grad_out && params && saved && work && grad_h && grads && (ew || L == 0), BSMS_E_INVALID_ARG,
+               "bsgmp_bwd: null argument");
+  hipStream_t st = as_stream(stream);
+  Work w = carve_work(work, s);
+  Saved v = carve_saved(const_cast<void*>(saved), s, true);
+  const float* pos_l[kMaxLevels + 1];
+  int64_t pstride_l[kMaxLevels + 1];
+  const float* hin_l[kMaxLevels + 1];
+  for (int i = 0; i <= L; ++i) {
+    pos_l[i] = i ? v.pos[i] : pos;
+    pstride_l[i] = i ? (pos_batch_stride ? s.N[i] * p : 0) : pos_batch_stride;
+    hin_l[i] = i ? v.hin[i] : h;
+  }
+  // up path, last block first.  The gradient reaching level d is both the up block's grad_out and the gradient of
+  // the skip connection s_d: it stays in w.skip[d] until the down path picks it up.
+  const float* g = grad_out;
+  const float* skip_grad[kMaxLevels];
+  for (int i = L - 1; i >= 0; --i) {
+    const int d = L - 1 - i;
+    skip_grad[d] = g;      // level 0: the caller's grad_out; deeper: w.skip[d], written by the level above
+    float* gu = w.a[0];    // gradient w.r.t. the up block's input u_d
+    if ((rc = bsms_gmp_bwd(plans[d], v.upin[d], pos_l[d], g, B, D, p, pstride_l[d], hidden, block(params, L + 1 + i, hidden),
+                           v.gmp[L + 1 + i], w.gmp, gu, block(grads, L + 1 + i, hidden), stream))) return rc;
+    // adjoint of prolong_d: a restrict-shaped gather onto level d + 1, kept for that level's skip connection
+    float* gnext = (d + 1 < L) ? w.skip[d + 1] : w.a[1];
+    if ((rc = bsms_edge_conv(plans[d], gu, B, D, ew[d], 1, 1, gnext, stream))) return rc;
+    g = gnext;
+  }
+  // bottom block
+  float* gb = w.a[0];
+  if ((rc = bsms_gmp_bwd(plans[L], hin_l[L], pos_l[L], g, B, D, p, pstride_l[L], hidden, block(params, L, hidden), v.gmp[L], w.gmp,
+                         (L == 0) ? grad_h : gb, block(grads, L, hidden), stream))) return rc;
+  const float* gl = gb;
+  for (int i = L - 1; i >= 0; --i) {
+    // adjoint of restrict_i, plus the gradient that arrived at the skip connection of level i
+    float* gs = w.a[1];
+    if ((rc = bsms_edge_conv(plans[i], gl, B, D, ew[i], 0, 1, gs, stream))) return rc;
+    if ((rc = add_rows(gs, skip_grad[i], gs, B * s.N[i] * D, st))) return rc;
+    float* gx = (i == 0) ? grad_h : w.a[0];
+    if ((rc = bsms_gmp_bwd(plans[i], hin_l[i], pos_l[i], gs, B, D, p, pstride_l[i], hidden, block(params, i, hidden), v.gmp[i], w.gmp,
+                           gx, block(grads, i, hidden), stream))) return rc;
+    gl = gx;
+  }
+  return BSMS_OK;
+}

@@ -18,6 +18,8 @@ from typing import Optional
 import torch
 from torch import nn
 
+import os
+
 from . import _abi
 from .graph import LevelPlan, plan_for
 
@@ -39,6 +41,9 @@ def _dev_f32(t, what):
 
 
 _WORK = {}
+# BSMS_PY_BSGMP=1: run the U-Net as the Python module tree of the reference (one autograd node per block / transition)
+# instead of the single bsms_bsgmp_fwd / _bwd call; same kernels, same results, ~3x the host time per step.
+_PY_BSGMP = os.environ.get("BSMS_PY_BSGMP", "0") == "1"
 
 
 def _workspace(device, nbytes):
@@ -413,6 +418,67 @@ class Unpool(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------- BSGMP
+class _BSGMPFunction(torch.autograd.Function):
+    """The whole U-Net as ONE autograd node (bsms_bsgmp_fwd / _bwd): two library calls per training step instead of
+    ~60 Python autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, h, pos, plans, ews, hidden, *params):
+        B, _, D = h.shape
+        p = pos.shape[-1]
+        pos_bstride = pos.shape[-2] * p if pos.dim() == 3 else 0
+        L = _abi.lib()
+        depth = len(plans) - 1
+        pl, keep_pl = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in plans])
+        ewp, keep_ew = _abi.ptr_array([e.data_ptr() for e in ews])
+        out = torch.empty_like(h)
+        saved = torch.empty(L.bsms_bsgmp_saved_bytes(pl, depth, B, D, p, hidden), dtype=torch.uint8, device=h.device)
+        work = _workspace(h.device, L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden))
+        pp, keep = _param_ptrs(params)
+        _abi.check(L.bsms_bsgmp_fwd(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
+                                    out.data_ptr(), saved.data_ptr(), work.data_ptr(), _stream()), "bsms_bsgmp_fwd")
+        ctx.save_for_backward(h, pos, saved, *ews)
+        ctx.params, ctx.plans, ctx.hidden = params, plans, hidden
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, pos, saved, *ews = ctx.saved_tensors
+        params, plans, hidden = ctx.params, ctx.plans, ctx.hidden
+        B, _, D = h.shape
+        p = pos.shape[-1]
+        pos_bstride = pos.shape[-2] * p if pos.dim() == 3 else 0
+        L = _abi.lib()
+        depth = len(plans) - 1
+        pl, keep_pl = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in plans])
+        ewp, keep_ew = _abi.ptr_array([e.data_ptr() for e in ews])
+        gout = gout.contiguous()
+        gh = torch.empty_like(h)
+        grads = _grad_targets(params)
+        work = _workspace(h.device, L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden))
+        pp, keep = _param_ptrs(params)
+        gp, keep2 = _param_ptrs(grads)
+        _abi.check(L.bsms_bsgmp_bwd(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), gout.data_ptr(), B, D, p, pos_bstride, hidden,
+                                    pp, saved.data_ptr(), work.data_ptr(), gh.data_ptr(), gp, _stream()), "bsms_bsgmp_bwd")
+        return (gh, None, None, None, None, *grads)
+
+
+def _bsgmp_infer(h, pos, plans, ews, hidden, params):
+    B, _, D = h.shape
+    p = pos.shape[-1]
+    pos_bstride = pos.shape[-2] * p if pos.dim() == 3 else 0
+    L = _abi.lib()
+    depth = len(plans) - 1
+    pl, keep_pl = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in plans])
+    ewp, keep_ew = _abi.ptr_array([e.data_ptr() for e in ews])
+    out = torch.empty_like(h)
+    work = _workspace(h.device, L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden))
+    pp, keep = _param_ptrs(params)
+    _abi.check(L.bsms_bsgmp_fwd(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
+                                out.data_ptr(), None, work.data_ptr(), _stream()), "bsms_bsgmp_fwd(inference)")
+    return out
+
+
 class BSGMP(nn.Module):
     """ops/BSMS.py:8-104: down pass (GMP, restrict), bottom GMP, up pass (prolong, GMP, skip add).
 
@@ -462,6 +528,21 @@ class BSGMP(nn.Module):
             plans.append(plan_for(m_gs[i], n_l, m_ids[i]))
             n_l = plans[-1].Nk
         ews = self._edge_weights(plans, m_ids, pos.device)
+        if not _PY_BSGMP:   # the whole U-Net in one library call (csrc/bsgmp.hip)
+            squeeze = h.dim() == 2
+            if squeeze:
+                if pos.dim() == 3:
+                    raise NotImplementedError("GMP: 2-D x with 3-D pos is not a layout of the reference")
+                h = h.unsqueeze(0)
+            all_plans = [*plans, plan_for(m_gs[L], n_l)]
+            blocks = [*self.down_gmps, self.bottom_gmp, *self.up_gmps]
+            params = [q for b in blocks for q in (*b.mlp_node.flat_params(), *b.mlp_edge.flat_params())]
+            hidden = self.bottom_gmp.hidden_layer
+            if _needs_grad(h, *params):
+                y = _BSGMPFunction.apply(h, pos, all_plans, ews, hidden, *params)
+            else:
+                y = _bsgmp_infer(h, pos, all_plans, ews, hidden, params)
+            return y.squeeze(0) if squeeze else y
         for i in range(L):
             plan = plans[i]
             h = self.down_gmps[i](h, m_gs[i], pos, plan=plan)

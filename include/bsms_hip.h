@@ -146,6 +146,25 @@ int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float* pos, cons
                  const float* const* params, const void* saved, void* work, float* grad_x,
                  float* const* grads, bsms_stream_t stream);
 
+/* ---------------------------------------------------------------- A9: BSGMP (whole U-Net) ---
+ * BSGMP.forward (ops/BSMS.py:39-104) in one call: down blocks + restrict, bottom block, prolong + up blocks + skip
+ * connections.  `plans`: L+1 HOST pointers, levels 0..L; levels < L have their pool attached (bsms_plan_set_pool with
+ * m_ids[l]) and plans[l]->Nk == nodes of level l+1.  `ew`: L HOST pointers to the DEVICE edge weights of levels 0..L-1
+ * (cal_ew chain, BSMS.py:64,73,89 -- mesh-static, the caller caches them).  h,out [B,N_0,D]; pos [B,N_0,p]
+ * (pos_batch_stride = N_0*p) or [N_0,p] (0).  `params`/`grads`: HOST arrays of (2L+1) x 4 (hidden+1) device
+ * pointers, blocks in the order down_gmps[0..L-1], bottom_gmp, up_gmps[0..L-1] (up_gmps[i] acts on level L-1-i,
+ * BSMS.py:96-101), each block laid out as for bsms_gmp_fwd.  `saved` = NULL selects inference. */
+size_t bsms_bsgmp_saved_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden);
+size_t bsms_bsgmp_work_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden);
+int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                   int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                   const float* const* params, float* out, void* saved, void* work, bsms_stream_t stream);
+int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                   const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                   const float* const* params, const void* saved, void* work, float* grad_h,
+                   float* const* grads, bsms_stream_t stream);
+
+
 /* ---------------------------------------------------------------- hierarchy builder (host) ---
  * BistrideMultiLayerGraph (graph_wrappers/bsms_graph_wrapper.py:8-154 + graph_wrapper.py:67-134): the
  * bi-stride multi-level hierarchy of a mesh, built natively on the HOST (no GPU needed, no SciPy/MKL).

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bsms_gnn_amd as eng
 from bench import build_workload, make_cfg, data_tuple
-wl = build_workload("airfoil", 8, "cuda")
+wl = build_workload(os.environ.get("WORKLOAD", "airfoil"), 8, "cuda")
 torch.manual_seed(0)
 sim = eng.BSMS_Simulator(make_cfg(wl["cfg"])).cuda()
 data = data_tuple(wl)
