@@ -315,6 +315,33 @@ def test_bsgmp_golden(eng, graphs, tag, D, p):
 
 
 # ------------------------------------------------------------------------------------ A10-A12, A16
+def test_bsgmp_single_call_equals_module_tree(eng, graphs):
+    """bsms_bsgmp_fwd/_bwd (one library call for the U-Net) sequences exactly the kernels the per-module Python tree
+    launches: outputs, input gradient and every parameter gradient must be bit-identical."""
+    from bsms_gnn_amd import ops
+    z = load_golden("bsgmp_del300")
+    L = int(z.np("depth"))
+    es, ids = graphs.levels(str(z.np("graph")))
+    net = load_sd(eng.BSGMP(L, 32, 3, 2), z.state_dict())
+    res = {}
+    for mode in (False, True):
+        ops._PY_BSGMP = mode
+        try:
+            net.zero_grad()
+            h = dev(z.t("h")).requires_grad_(True)
+            y = net(h, [dev(i) for i in ids[:L]], [dev(e) for e in es[: L + 1]], dev(z.t("pos")))
+            (y * dev(z.t("cot"))).sum().backward()
+            with torch.no_grad():
+                yi = net(h.detach(), [dev(i) for i in ids[:L]], [dev(e) for e in es[: L + 1]], dev(z.t("pos")))
+            res[mode] = (y.detach().clone(), h.grad.clone(), [q.grad.clone() for q in net.parameters()], yi.clone())
+        finally:
+            ops._PY_BSGMP = False
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+    assert rel_err(a[0].cpu(), z.t("y")) < FWD_TOL
+
+
 def test_simulator_step_and_rollout_golden(eng, graphs):
     z = load_golden("sim")
     es, ids = graphs.levels("del300")
