@@ -140,22 +140,30 @@ extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* cons
   Saved v = training ? carve_saved(saved, s, true) : carve_saved(reinterpret_cast<char*>(work) + w.bytes, s, false);
   const int64_t posB = pos_batch_stride ? B : 1;   // a 2-D pos is shared by the batch (ops/basic.py:87-88)
 
-  const float* hi = h;
-  const float* pi = pos;
-  int64_t pstride = pos_batch_stride;
+  // Positions of all coarse levels first, on a side stream: they depend on pos and ew only (ops/BSMS.py:75,85-88)
+  // and are five latency-bound launches that would otherwise sit between the blocks; joined before level 1 needs them.
   const float* pos_l[kMaxLevels + 1];
   int64_t pstride_l[kMaxLevels + 1];
-  for (int i = 0; i < L; ++i) {
-    pos_l[i] = pi; pstride_l[i] = pstride;
-    if ((rc = bsms_gmp_fwd(plans[i], hi, pi, B, D, p, pstride, hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp, stream))) return rc;
-    // restrict features and positions to the kept nodes (ops/BSMS.py:74-75, 79-88)
-    if ((rc = bsms_edge_conv(plans[i], w.skip[i], B, D, ew[i], 1, 1, v.hin[i + 1], stream))) return rc;
-    if ((rc = bsms_edge_conv(plans[i], pi, posB, p, ew[i], 1, 1, v.pos[i + 1], stream))) return rc;
-    hi = v.hin[i + 1];
-    pi = v.pos[i + 1];
-    pstride = pos_batch_stride ? s.N[i + 1] * p : 0;
+  pos_l[0] = pos; pstride_l[0] = pos_batch_stride;
+  SideLane* lane = nullptr;
+  if (L > 0) {
+    if ((rc = side_lane(&lane, 1)) || (rc = side_fork(lane, st))) return rc;
+    for (int i = 0; i < L; ++i) {
+      if ((rc = bsms_edge_conv(plans[i], pos_l[i], posB, p, ew[i], 1, 1, v.pos[i + 1], lane->stream))) return rc;
+      pos_l[i + 1] = v.pos[i + 1];
+      pstride_l[i + 1] = pos_batch_stride ? s.N[i + 1] * p : 0;
+    }
   }
-  pos_l[L] = pi; pstride_l[L] = pstride;
+  const float* hi = h;
+  for (int i = 0; i < L; ++i) {
+    if ((rc = bsms_gmp_fwd(plans[i], hi, pos_l[i], B, D, p, pstride_l[i], hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp, stream))) return rc;
+    if (i == 0 && (rc = side_join(lane, st))) return rc;
+    // restrict the features to the kept nodes (ops/BSMS.py:74, 79-83)
+    if ((rc = bsms_edge_conv(plans[i], w.skip[i], B, D, ew[i], 1, 1, v.hin[i + 1], stream))) return rc;
+    hi = v.hin[i + 1];
+  }
+  const float* pi = pos_l[L];
+  const int64_t pstride = pstride_l[L];
   float* cur = (L == 0) ? out : w.a[0];
   if ((rc = bsms_gmp_fwd(plans[L], hi, pi, B, D, p, pstride, hidden, block(params, L, hidden), cur, v.gmp[L], w.gmp, stream))) return rc;
   for (int i = 0; i < L; ++i) {
