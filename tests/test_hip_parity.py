@@ -342,6 +342,40 @@ def test_bsgmp_single_call_equals_module_tree(eng, graphs):
     assert rel_err(a[0].cpu(), z.t("y")) < FWD_TOL
 
 
+def test_bsgmp_single_call_layouts(eng):
+    """The one-call U-Net against the module tree on the layouts the reference accepts: depth 0 (bottom block only),
+    2-D h with 2-D pos, 3-D h with a 2-D pos shared by the batch (ops/basic.py:87-88) -- bit-identical each time."""
+    from bsms_gnn_amd import ops
+    N, D = 120, 32
+    src = np.arange(N); dst = (src + 1) % N
+    flat = np.stack([np.concatenate([src, dst]), np.concatenate([dst, src])])
+    pts = np.stack([np.cos(2 * np.pi * src / N), np.sin(2 * np.pi * src / N)], 1)
+    _, m_es, m_ids = eng.BistrideMultiLayerGraph(flat, 2, N, pts).get_multi_layer_graphs()
+    m_gs = [dev(torch.tensor(e, dtype=torch.int64)) for e in m_es]
+    ids = [dev(torch.tensor(i, dtype=torch.int64)) for i in m_ids]
+    pos2 = dev(torch.tensor(pts, dtype=torch.float32))
+    torch.manual_seed(0)
+    cases = [(eng.BSGMP(0, D, 2, 2), torch.randn(2, N, D), [], m_gs[:1], dev(torch.rand(2, N, 2))),
+             (eng.BSGMP(2, D, 2, 2), torch.randn(N, D), ids, m_gs, pos2),
+             (eng.BSGMP(2, D, 2, 2), torch.randn(3, N, D), ids, m_gs, pos2)]
+    for net, h0, i_, g_, pos in cases:
+        net = net.cuda()
+        res = {}
+        for mode in (False, True):
+            ops._PY_BSGMP = mode
+            try:
+                net.zero_grad()
+                h = dev(h0).requires_grad_(True)
+                y = net(h, i_, g_, pos)
+                y.square().sum().backward()
+                res[mode] = (y.detach().clone(), h.grad.clone(), [q.grad.clone() for q in net.parameters()])
+            finally:
+                ops._PY_BSGMP = False
+        a, b = res[False], res[True]
+        assert a[0].shape == h0.shape and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+
+
 def test_simulator_step_and_rollout_golden(eng, graphs):
     z = load_golden("sim")
     es, ids = graphs.levels("del300")
