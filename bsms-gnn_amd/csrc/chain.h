@@ -170,5 +170,6 @@ int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s);
 // from rowsum.hip
 int rowsum_plan_order(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
 int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
+int rowsum_source_and_target(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD, hipStream_t s);
 
 }  // namespace bsms

@@ -304,8 +304,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     s2 = lane2->stream;
   }
   // gradient of the first edge Linear w.r.t. the two per-node projections
-  if ((rc = rowsum_by_source(plan, wk.gE[0], B, D, wk.dPs, s))) return rc;
-  if ((rc = rowsum_plan_order(plan, wk.gE[0], B, D, wk.dPd, s))) return rc;
+  if ((rc = rowsum_source_and_target(plan, wk.gE[0], B, D, wk.dPs, wk.dPd, s))) return rc;   // one launch for both
   // fiber columns of W0_edge and its bias
   {
     SmallWgradArgs a{};

@@ -114,6 +114,15 @@ __global__ __launch_bounds__(256) void k_rowsum_v4(RowSumArgs a) {
   }
 }
 
+// two unweighted, unmapped sums of the SAME shape in one launch (blockIdx.y picks the job): the scatters of the first
+// edge gradient to its source and to its target rows
+template <int LPR, bool DEEP>
+__global__ __launch_bounds__(256) void k_rowsum_pair(RowSumArgs a0, RowSumArgs a1) {
+  const RowSumArgs& a = blockIdx.y ? a1 : a0;
+  if (a.xidx) rowsum_body<LPR, false, false, DEEP, true, false>(a);
+  else rowsum_body<LPR, false, false, DEEP, false, false>(a);
+}
+
 // any D (positions: D = 2 or 3): one thread per output element
 template <bool WEIGHTED, bool MAPPED>
 __global__ __launch_bounds__(256) void k_rowsum_scalar(RowSumArgs a) {
@@ -244,6 +253,26 @@ int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, f
   a.x_bstride = p->E * D; a.out_bstride = p->N * D;
   a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
   return launch_rowsum(a, s);
+}
+// by source and by target at once: outS[b,i,:] = sum_{e: src(e)=i} x[b,slot(e),:], outD[b,j,:] = sum_{e: dst(e)=j} x[b,slot(e),:]
+int rowsum_source_and_target(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD, hipStream_t s) {
+  if (D != 128) {   // the pair kernel is built for the 32-lanes-per-row shape only
+    int rc = rowsum_by_source(p, x, B, D, outS, s);
+    return rc ? rc : rowsum_plan_order(p, x, B, D, outD, s);
+  }
+  RowSumArgs a0{}, a1{};
+  a0.rowptr = p->t_rowptr; a0.xidx = p->t_pos;
+  a1.rowptr = p->rowptr;
+  a0.x = a1.x = x; a0.out = outS; a1.out = outD;
+  a0.x_bstride = a1.x_bstride = p->E * D; a0.out_bstride = a1.out_bstride = p->N * D;
+  a0.n_out = a1.n_out = (int32_t)p->N; a0.B = a1.B = (int32_t)B; a0.D = a1.D = (int32_t)D;
+  const int64_t workers = B * p->N;
+  if (workers == 0) return BSMS_OK;
+  const dim3 grid((unsigned)ceil_div(workers * 32, 256), 2);
+  if (workers * 32 < kDeepBelowThreads) hipLaunchKernelGGL((k_rowsum_pair<32, true>), grid, dim3(256), 0, s, a0, a1);
+  else hipLaunchKernelGGL((k_rowsum_pair<32, false>), grid, dim3(256), 0, s, a0, a1);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
 }
 }  // namespace bsms
 
