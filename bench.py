@@ -28,9 +28,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WORKLOADS = {
-    "cylinder": dict(nodes=1885, levels=4, out_dim=2, pos_dim=2, latent=128),
-    "airfoil": dict(nodes=5233, levels=5, out_dim=3, pos_dim=2, latent=128),
+WORKLOADS = {  # SURVEY.md section 8(d); BASELINE.json configs[1], [2]/[3], [4]
+    "cylinder": dict(nodes=1885, levels=4, out_dim=2, pos_dim=2, latent=128, mesh_seed=0),
+    "airfoil": dict(nodes=5233, levels=5, out_dim=3, pos_dim=2, latent=128, mesh_seed=0),
+    # inflating-surface stand-in: 16384 nodes on z = sin(3u) cos(3v), 3-D positions, 6 levels, D=256.  Mesh seed 1:
+    # with seed 0 the level-5 graph is complete, its BFS keeps ONE node and level 6 degenerates to N=1, E=0
+    # (SURVEY.md section 8 table); seed 1 bottoms out at 88 nodes / 4796 edges (validated by validate_hierarchy).
+    "surface": dict(nodes=16384, levels=6, out_dim=3, pos_dim=3, latent=256, mesh_seed=1),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate
@@ -38,23 +42,62 @@ MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 flop/cyc
 MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 6  # fp32 by exact 3-way bf16 split = six bf16 products per fp32 MAC
 
 
-def build_mesh(kind):
-    """Synthetic Delaunay stand-in for the dataset mesh + its bi-stride hierarchy (host, once)."""
+def mesh_points(kind, seed=None):
+    """Node positions [N,p] (fp64) and the triangulation of the synthetic stand-in mesh."""
     from scipy.spatial import Delaunay
+    w = WORKLOADS[kind]
+    uv = np.random.default_rng(w["mesh_seed"] if seed is None else seed).random((w["nodes"], 2))
+    cells = Delaunay(uv).simplices.astype(np.int64)
+    if w["pos_dim"] == 3:
+        uv = np.concatenate([uv, (np.sin(3 * uv[:, 0]) * np.cos(3 * uv[:, 1]))[:, None]], 1)
+    return uv, cells
+
+
+def validate_hierarchy(kind, m_es, m_ids):
+    """A usable hierarchy: every level has >= 2 nodes, >= 1 edge, every node an out-edge (degree() quirk,
+    utils/basic.py:305) and the level sizes chain (len(m_ids[l]) nodes at level l+1)."""
+    n = WORKLOADS[kind]["nodes"]
+    for l, e in enumerate(m_es):
+        if n < 2 or e.shape[1] < 1:
+            raise ValueError(f"{kind}: level {l} is degenerate (N={n}, E={e.shape[1]}); pick another mesh seed / depth")
+        if int(e.max()) >= n or len(np.unique(e[0])) != n:
+            raise ValueError(f"{kind}: level {l} has a node without an out-edge or an index out of range")
+        if l < len(m_ids):
+            n = len(m_ids[l])
+
+
+def build_mesh(kind, seed=None):
+    """Synthetic Delaunay stand-in for the dataset mesh + its bi-stride hierarchy (host, once)."""
     from bsms_gnn_amd.hierarchy import BistrideMultiLayerGraph, to_flat_edge
     w = WORKLOADS[kind]
-    pts = np.random.default_rng(0).random((w["nodes"], 2))
-    cells = Delaunay(pts).simplices.astype(np.int64)
+    pts, cells = mesh_points(kind, seed)
     flat = to_flat_edge(cells, "tri")
     _, m_es, m_ids = BistrideMultiLayerGraph(flat, w["levels"], w["nodes"], pts).get_multi_layer_graphs()
+    validate_hierarchy(kind, m_es, m_ids)
     return pts, m_es, m_ids
 
 
-def build_workload(kind, batch, device, seed=0):
+def strip_mesh(nx=327, ny=16, levels=7):
+    """Structured, jittered triangle strip (nx*ny nodes).  A uniform random 5k-node Delaunay mesh collapses to one
+    node at level 6, so the reference's DEFAULT depth (configs/model/airfoil.yaml:4 `unet_depth: 7`) needs a mesh
+    with a large graph diameter, like the real (graded, elongated) airfoil mesh: 327 x 16 -> 32 nodes at level 7."""
+    from bsms_gnn_amd.hierarchy import BistrideMultiLayerGraph, to_flat_edge
+    xs, ys = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    idx = xs * ny + ys
+    pts = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.float64) + 0.2 * np.random.default_rng(0).random((nx * ny, 2))
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    cells = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)]).astype(np.int64)
+    w = dict(WORKLOADS["airfoil"], nodes=nx * ny, levels=levels)
+    _, m_es, m_ids = BistrideMultiLayerGraph(to_flat_edge(cells, "tri"), levels, nx * ny, pts).get_multi_layer_graphs()
+    return w, (pts / ny, m_es, m_ids)
+
+
+def build_workload(kind, batch, device, seed=0, mesh=None, cfg=None):
     """Consistent-mesh batch exactly as the reference collates it (datasets/base.py:319-351 + default
-    collate): node_in [B,N,C+p+1] = [state, mesh_pos, node_type], every m_gs[l] as [B,2,E_l]."""
-    w = WORKLOADS[kind]
-    pts, m_es, m_ids = build_mesh(kind)
+    collate): node_in [B,N,C+p+1] = [state, mesh_pos, node_type], every m_gs[l] as [B,2,E_l].
+    `mesh` = (pts, m_es, m_ids) with its own `cfg` dict overrides the named workload's mesh."""
+    w = WORKLOADS[kind] if cfg is None else cfg
+    pts, m_es, m_ids = build_mesh(kind) if mesh is None else mesh
     n, c = w["nodes"], w["out_dim"]
     gen = torch.Generator().manual_seed(seed)
     state = torch.randn(batch, n, c, generator=gen)
@@ -72,16 +115,13 @@ def build_workload(kind, batch, device, seed=0):
 def build_blockdiag_workload(kind, batch, device):
     """Variable-mesh layout (the reference's cylinder_flow path, consistent_mesh: false): `batch` DIFFERENT meshes
     (Delaunay seeds 0..batch-1), collated into one block-diagonal graph per level (A15)."""
-    from scipy.spatial import Delaunay
     import bsms_gnn_amd as eng
     w = WORKLOADS[kind]
     n, c = w["nodes"], w["out_dim"]
     gen = torch.Generator().manual_seed(0)
     samples = []
     for seed in range(batch):
-        pts = np.random.default_rng(seed).random((n, 2))
-        flat = eng.to_flat_edge(Delaunay(pts).simplices.astype(np.int64), "tri")
-        _, m_es, m_ids = eng.BistrideMultiLayerGraph(flat, w["levels"], n, pts).get_multi_layer_graphs()
+        pts, m_es, m_ids = build_mesh(kind, seed=seed)
         state, target = torch.randn(n, c, generator=gen), torch.randn(n, c, generator=gen)
         x = torch.cat([state, torch.tensor(pts, dtype=torch.float32), torch.zeros(n, 1)], -1)
         sizes = [n] + [len(i) for i in m_ids]

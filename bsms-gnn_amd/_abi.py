@@ -47,6 +47,7 @@ SIGNATURES = {
     "bsms_bsgmp_bwd": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
                                c_void_p, c_void_p, PP, c_void_p]),
     "bsms_hierarchy_create": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, PP]),
+    "bsms_hierarchy_create_f32": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, PP]),
     "bsms_hierarchy_destroy": (c_int, [c_void_p]),
     "bsms_hierarchy_level_nodes": (c_i64, [c_void_p, c_int]),
     "bsms_hierarchy_level_edges": (c_i64, [c_void_p, c_int]),

@@ -2,7 +2,8 @@
 // (graph_wrappers/graph_wrapper.py:67-134, list.pop(0) frontier), its MKL SpGEMM dependency
 // (sparse_dot_mkl.dot_product_mkl, bsms_graph_wrapper.py:99-100) and the NumPy renumbering (:129-154).
 // Per level: components by reachability from the smallest unassigned node -> seed = member nearest the
-// component centroid (first on ties; fp64 arithmetic in NumPy's evaluation order so the argmin is bit-equal) ->
+// component centroid (first on ties; arithmetic in the DTYPE OF THE POSITIONS -- fp32 or fp64 -- and in NumPy's
+// evaluation order, so the argmin is bit-equal to the reference's np.mean / np.linalg.norm / np.argmin) ->
 // BFS hop parity -> keep the SMALLER parity class (ties / empty odd class keep even) -> coarse edges = pattern of
 // (A+I)^2 minus the diagonal among kept nodes, renumbered by rank, emitted row-major with sorted columns.
 #include <algorithm>
@@ -54,7 +55,8 @@ void bfs(const Csr& g, int64_t seed, std::vector<int64_t>& depth, std::vector<in
   }
 }
 
-void one_level(const std::vector<int64_t>& s, const std::vector<int64_t>& d, int64_t n, const std::vector<double>& pos,
+template <typename T>   // T = dtype of the mesh positions (the reference computes in whatever dtype pos_mesh has)
+void one_level(const std::vector<int64_t>& s, const std::vector<int64_t>& d, int64_t n, const std::vector<T>& pos,
                int p, std::vector<int64_t>& keep, std::vector<int64_t>& cs, std::vector<int64_t>& cd) {
   const Csr g = build_csr(s, d, n);
   std::vector<int64_t> depth(n), queue;
@@ -74,20 +76,24 @@ void one_level(const std::vector<int64_t>& s, const std::vector<int64_t>& d, int
     }
     for (int64_t v : members) assigned[v] = 1;
     remaining -= (int64_t)members.size();
-    // seed: nearest to the centroid (np.mean(axis=0) = sequential sum / count; np.linalg.norm = sqrt(sum x^2))
-    double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // seed: nearest to the centroid (bsms_graph_wrapper.py:118-124).  np.mean(axis=0) of an [M,p] array adds the rows
+    // sequentially in T and divides by T(M); np.linalg.norm(., 2, axis=-1) = sqrt(sum x*x) in T, p < 8 terms added in
+    // order; np.argmin takes the first minimum.  Every operation below is one rounding in T (no contraction:
+    // host code, and the product is stored before the add).
+    T c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t v : members)
-      for (int k = 0; k < p; ++k) c[k] += pos[v * p + k];
-    for (int k = 0; k < p; ++k) c[k] /= (double)members.size();
+      for (int k = 0; k < p; ++k) c[k] = T(c[k] + pos[v * p + k]);
+    for (int k = 0; k < p; ++k) c[k] = T(c[k] / T(members.size()));
     int64_t seed = members[0];
-    double best = INFINITY;
+    T best = INFINITY;
     for (int64_t v : members) {
-      double s2 = 0.0;
+      T s2 = 0;
       for (int k = 0; k < p; ++k) {
-        const double t = std::fabs(pos[v * p + k] - c[k]);
-        s2 += t * t;
+        const T t = T(pos[v * p + k] - c[k]);
+        volatile T sq = T(t * t);   // rounded product, then the add: never an fma
+        s2 = T(s2 + sq);
       }
-      const double dist = std::sqrt(s2);
+      const T dist = std::sqrt(s2);
       if (dist < best) {
         best = dist;
         seed = v;
@@ -135,8 +141,10 @@ void one_level(const std::vector<int64_t>& s, const std::vector<int64_t>& d, int
 
 }  // namespace
 
-extern "C" int bsms_hierarchy_create(const int64_t* coo, int64_t E, int64_t N, const double* pos, int64_t pos_dim,
-                                     int num_layers, bsms_hierarchy_t** out) {
+namespace {
+template <typename T>
+int hierarchy_create_t(const int64_t* coo, int64_t E, int64_t N, const T* pos, int64_t pos_dim, int num_layers,
+                       bsms_hierarchy_t** out) {
   BSMS_REQUIRE(out != nullptr, BSMS_E_INVALID_ARG, "hierarchy_create: out is null");
   *out = nullptr;
   BSMS_REQUIRE(E >= 0 && N >= 0 && num_layers >= 0, BSMS_E_SHAPE, "hierarchy_create: negative size");
@@ -149,11 +157,11 @@ extern "C" int bsms_hierarchy_create(const int64_t* coo, int64_t E, int64_t N, c
   h->src.emplace_back(coo, coo + E);
   h->dst.emplace_back(coo + E, coo + 2 * E);
   h->nodes.push_back(N);
-  std::vector<double> p(pos, pos + N * pos_dim);
+  std::vector<T> p(pos, pos + N * pos_dim);
   for (int l = 0; l < num_layers; ++l) {
     std::vector<int64_t> keep, cs, cd;
-    one_level(h->src[l], h->dst[l], h->nodes[l], p, (int)pos_dim, keep, cs, cd);
-    std::vector<double> np(keep.size() * pos_dim);
+    one_level<T>(h->src[l], h->dst[l], h->nodes[l], p, (int)pos_dim, keep, cs, cd);
+    std::vector<T> np(keep.size() * pos_dim);
     for (size_t k = 0; k < keep.size(); ++k)
       for (int c = 0; c < pos_dim; ++c) np[k * pos_dim + c] = p[keep[k] * pos_dim + c];
     p.swap(np);
@@ -164,6 +172,16 @@ extern "C" int bsms_hierarchy_create(const int64_t* coo, int64_t E, int64_t N, c
   }
   *out = h;
   return BSMS_OK;
+}
+}  // namespace
+
+extern "C" int bsms_hierarchy_create(const int64_t* coo, int64_t E, int64_t N, const double* pos, int64_t pos_dim,
+                                     int num_layers, bsms_hierarchy_t** out) {
+  return hierarchy_create_t<double>(coo, E, N, pos, pos_dim, num_layers, out);
+}
+extern "C" int bsms_hierarchy_create_f32(const int64_t* coo, int64_t E, int64_t N, const float* pos, int64_t pos_dim,
+                                         int num_layers, bsms_hierarchy_t** out) {
+  return hierarchy_create_t<float>(coo, E, N, pos, pos_dim, num_layers, out);
 }
 
 extern "C" int bsms_hierarchy_destroy(bsms_hierarchy_t* h) {

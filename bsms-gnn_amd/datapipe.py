@@ -6,10 +6,14 @@ by the reference load unchanged, base.py:98-122), field packing `[outputs..., me
 the dataset masks (airfoil: type 0; cylinder: type 0 or 5), the training-noise injection (base.py:257-273) and the
 per-sample packing for consistent / variable meshes (base.py:319-351).
 
-Parity status: UNPINNED.  The reference datapipe imports h5py, torchdata and torch_geometric, none of which exist
-in this image, so no golden vectors could be generated for it; the semantics above are restated from the source and
-covered by self-consistency tests only (tests/test_datapipe.py).  Trajectories are read from `.npz` files or
-in-memory dicts; `.h5` files are read when h5py is importable.
+Parity status: PINNED.  The reference datapipe imports h5py, torchdata and torch_geometric, which this image lacks;
+tests/golden/make_golden_r2.py imports it with three stub modules (an h5py.File backed by .npz, an empty
+IterDataPipe base, an attribute-bag torch_geometric.data.Data) and records what `airfoilDataPipe` / `cylinderDataPipe`
+yield on small synthetic trajectories -- packed fields, masks, the seeded training noise, the (always shuffled) frame
+order, rollout frames and the per-level Data lists -- into tests/golden/datapipe.npz; tests/test_datapipe.py requires
+bit-equal output from this module.  Not pinned (third-party, absent): PyG's Batch collation (pinned by the
+batched == per-graph equivalence fixture instead) and real HDF5 decoding.  Trajectories are read from `.npz` files
+or in-memory dicts; `.h5` files are read when h5py is importable.
 """
 import glob
 import os
@@ -106,8 +110,11 @@ def pack_levels(node_in, node_tar, node_mask, m_gs, m_ids):
 
 
 class TrajectoryDataset(torch.utils.data.IterableDataset):
-    """base.py:128-357 without the torchdata dependency: iterates (shuffled when training) over trajectories and
-    frames; yields the consistent-mesh tuple or a per-level LevelData list; `mode="rollout"` yields whole trajectories."""
+    """base.py:128-357 without the torchdata dependency: iterates over trajectories and frames, yields the
+    consistent-mesh tuple or a per-level LevelData list; `mode="rollout"` yields whole trajectories.  Like the
+    reference, trajectories AND frames are shuffled in every mode (its `if self.rng is not None` guards are always
+    true, base.py:300-314), frames stay ordered only in rollout mode; noise is injected in train mode only.
+    `seed` is what the reference derives as train_seed + 1000 * worker_id + 10^6 * base_seed (base.py:176-183)."""
 
     def __init__(self, cfg, sources, dataset="airfoil", mode="train", seed=0, cache_dir=None):
         self.cfg, self.sources, self.mode, self.cache_dir = cfg, list(sources), mode, cache_dir
@@ -122,16 +129,14 @@ class TrajectoryDataset(torch.utils.data.IterableDataset):
     def __iter__(self):
         train, rollout = self.mode == "train", self.mode == "rollout"
         order = list(range(len(self.sources)))
-        if train:
-            self.rng.shuffle(order)
+        self.rng.shuffle(order)
         for si in order:
             reader = SingleTrajReader(self.cfg, self.sources[si], self.mode, self.cache_dir)
             t_ids = np.arange(len(reader))
             if rollout:
                 yield (*proc_data(self.cfg, reader[t_ids], self.mask_fn, False), reader.m_gs, reader.m_ids)
                 continue
-            if train:
-                self.rng.shuffle(t_ids)
+            self.rng.shuffle(t_ids)
             for ti in t_ids:
                 node_in, node_tar, node_mask = proc_data(self.cfg, reader[int(ti)], self.mask_fn, train, self.tc_rng)
                 if self.cfg.consist_mesh:

@@ -97,10 +97,14 @@ def _native_hierarchy(flat_edge, num_layers, num_nodes, pos_mesh):
     from . import _abi
     L = _abi.lib()
     coo = np.ascontiguousarray(flat_edge, dtype=np.int64)
-    pos = np.ascontiguousarray(pos_mesh, dtype=np.float64)
+    # the seed arithmetic runs in the dtype of the positions, like the reference's NumPy expression
+    # (bsms_graph_wrapper.py:118-124): float32 mesh_pos from the datapipe stays float32
+    f32 = np.asarray(pos_mesh).dtype == np.float32
+    pos = np.ascontiguousarray(pos_mesh, dtype=np.float32 if f32 else np.float64)
     h = C.c_void_p()
-    _abi.check(L.bsms_hierarchy_create(coo.ctypes.data, coo.shape[1], num_nodes, pos.ctypes.data, pos.shape[1], num_layers,
-                                       C.byref(h)), "bsms_hierarchy_create")
+    create = L.bsms_hierarchy_create_f32 if f32 else L.bsms_hierarchy_create
+    _abi.check(create(coo.ctypes.data, coo.shape[1], num_nodes, pos.ctypes.data, pos.shape[1], num_layers, C.byref(h)),
+               "bsms_hierarchy_create")
     try:
         es, ids = [], []
         for l in range(num_layers + 1):

@@ -168,13 +168,19 @@ int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* const* ew, int 
 /* ---------------------------------------------------------------- hierarchy builder (host) ---
  * BistrideMultiLayerGraph (graph_wrappers/bsms_graph_wrapper.py:8-154 + graph_wrapper.py:67-134): the
  * bi-stride multi-level hierarchy of a mesh, built natively on the HOST (no GPU needed, no SciPy/MKL).
- * Inputs are HOST pointers: coo int64 [2,E] (level-0 flat edges), pos fp64 [N,pos_dim].  Level l has
+ * Inputs are HOST pointers: coo int64 [2,E] (level-0 flat edges), pos [N,pos_dim] in fp64 (bsms_hierarchy_create) or
+ * fp32 (bsms_hierarchy_create_f32).  The seed of a cluster is the node nearest its centroid
+ * (bsms_graph_wrapper.py:118-124) and the reference evaluates that in the dtype of `pos_mesh` (datasets/base.py hands
+ * it float32 mesh_pos): the two entries do the arithmetic in fp64 / fp32 respectively, in NumPy's evaluation order, so
+ * the argmin -- hence m_ids -- is bit-exact for either dtype.  Level l has
  * level_nodes(l) nodes and level_edges(l) directed edges; copy_edges writes int64 [2,E_l] (level 0: the
  * caller's edges unchanged; coarser levels row-major with sorted columns), copy_ids writes the kept node
  * ids of level l (ascending, relative to level l; `m_ids[l]`), bit-exact w.r.t. the reference. */
 typedef struct bsms_hierarchy bsms_hierarchy_t;
 int bsms_hierarchy_create(const int64_t* coo_host, int64_t E, int64_t N, const double* pos_host,
                           int64_t pos_dim, int num_layers, bsms_hierarchy_t** out);
+int bsms_hierarchy_create_f32(const int64_t* coo_host, int64_t E, int64_t N, const float* pos_host,
+                              int64_t pos_dim, int num_layers, bsms_hierarchy_t** out);
 int bsms_hierarchy_destroy(bsms_hierarchy_t* h);
 int64_t bsms_hierarchy_level_nodes(const bsms_hierarchy_t* h, int level);
 int64_t bsms_hierarchy_level_edges(const bsms_hierarchy_t* h, int level);

@@ -118,7 +118,7 @@ def edge_conv(x, g, ew, aggragating=True):
 def cal_ew(w, g):
     """WeightedEdgeConv.cal_ew (ops/basic.py:142-167). Returns (ec [E], aggr_w [N] incl. 1e-12)."""
     send, recv = g[0], g[1]
-    share = w.squeeze(-1) / degree(send, dtype=torch.float)                 # :159-160
+    share = w.squeeze(-1) / degree(send, dtype=torch.float)                 # :159-160 (fp64 w promotes: exact leg)
     sent = share[send]                                                       # :162
     aggr_w = scatter_sum(sent, recv, dim=-1, dim_size=share.size(0)) + 1e-12  # :163-164
     return sent / aggr_w[recv], aggr_w                                       # :165
@@ -182,10 +182,11 @@ class BSGMP(nn.Module):
 class Normalizer(nn.Module):
     """Online mean / mean-of-squares in fp64 (utils/normalizer.py:9-90); state keys as the reference."""
 
-    def __init__(self, size, max_accumulations=10**6, std_epsilon=1e-8, unit=10**6):
+    def __init__(self, size, max_accumulations=10**6, std_epsilon=1e-8, unit=10**6, out_dtype=torch.float32):
         super().__init__()
         f64 = dict(dtype=torch.float64)
         self.size, self.unit = size, unit
+        self.out_dtype = out_dtype   # fp32 like the reference; fp64 only for the "exact" leg of the three-way gradient tests
         mk = lambda t: nn.Parameter(t, requires_grad=False)
         self.std_eps = mk(torch.tensor(std_epsilon, **f64))
         self._max_accumulations = mk(torch.tensor(max_accumulations, **f64))
@@ -214,10 +215,10 @@ class Normalizer(nn.Module):
     def forward(self, batch, accumulate=False):                               # :40-52
         if accumulate and bool(self._num_accumulations < self._max_accumulations):
             self.accumulate(batch)
-        return ((batch - self._E_data) / self.std_with_epsilon()).type(torch.float32)
+        return ((batch - self._E_data) / self.std_with_epsilon()).type(self.out_dtype)
 
     def inverse(self, batch):                                                 # :80-83
-        return ((batch * self.std_with_epsilon()) + self._E_data).type(torch.float32)
+        return ((batch * self.std_with_epsilon()) + self._E_data).type(self.out_dtype)
 
 
 # --------------------------------------------------------------------------------------------
@@ -228,15 +229,17 @@ class Normalizer(nn.Module):
 class BSMS_Simulator(nn.Module):
     """normalise -> encode -> BSGMP -> decode -> de-normalise -> mask -> integrate (models/model.py)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, dtype=torch.float32):
+        """`dtype`: arithmetic of the network.  fp32 = the reference; fp64 (weights cast with .double(), fp64 inputs)
+        is the near-exact leg the full-size gradient tests measure both fp32 implementations against."""
         super().__init__()
         self.cfg = cfg
         self.pos_dim = cfg.pos_dim
         self.encode = MLP(cfg.out_dim + 1, cfg.latent_dim, cfg.latent_dim, cfg.hidden_layer, True)
         self.process = BSGMP(cfg.unet_depth, cfg.latent_dim, cfg.hidden_layer, cfg.pos_dim)
         self.decode = MLP(cfg.latent_dim, cfg.latent_dim, cfg.out_dim, cfg.hidden_layer, False)
-        self._inputNormalizer = Normalizer(cfg.out_dim + 1, max_accumulations=5e5)
-        self._targetNormalizer = Normalizer(cfg.out_dim, max_accumulations=5e5)
+        self._inputNormalizer = Normalizer(cfg.out_dim + 1, max_accumulations=5e5, out_dtype=dtype)
+        self._targetNormalizer = Normalizer(cfg.out_dim, max_accumulations=5e5, out_dtype=dtype)
 
     def split(self, node_in):
         """node_in[..., :C] state | [..., C:C+p] mesh_pos | [..., -1] node_type (model.py:43-46,62)."""

@@ -152,3 +152,46 @@ def test_product_collate_equals_oracle_collate(eng, graphs):
     for l in range(2):
         assert torch.equal(batch[l].face, o_ids[l]) and torch.equal(batch[l].face, z.t(f"cat/ids{l}"))
     assert batch[2].face is None and batch[0].x.shape[0] == 364
+
+
+F32_CASES = [("grid20x20", "quad"), ("grid31x17", "quad"), ("grid40x25", "quad"), ("grid16x8", "quad"), ("del300f", "tri"),
+             ("del500f", "tri"), ("surf200f", "tri")]
+
+
+@pytest.mark.parametrize("name,kind", F32_CASES)
+def test_hierarchy_from_float32_positions(eng, name, kind):
+    """datasets/base.py:47 hands the builder FLOAT32 mesh positions and the reference picks each cluster's seed with
+    NumPy arithmetic in that dtype (bsms_graph_wrapper.py:118-124).  Structured grids are full of near-ties, where
+    fp64 arithmetic picks a different seed -> different m_ids.  Golden: tests/golden/graphs_f32.npz (generated from the
+    reference with float32 positions); native C++ builder, SciPy builder and the oracle must all be bit-exact."""
+    from conftest import load_golden
+    z = load_golden("graphs_f32")
+    es, ids = z.levels(name)
+    pos = z.np(f"{name}/pos")
+    assert pos.dtype == np.float32
+    fe = eng.to_flat_edge(z.np(f"{name}/cells"), kind)
+    assert np.array_equal(fe, es[0].numpy())
+    for backend in ("native", "scipy"):
+        _, m_es, m_ids = eng.BistrideMultiLayerGraph(fe, 3, pos.shape[0], pos, backend=backend).get_multi_layer_graphs()
+        for l, (mine, ref) in enumerate(zip(m_ids, ids)):
+            assert np.array_equal(mine, ref.numpy()), (backend, l)
+        for l in range(1, 4):
+            assert np.array_equal(np.asarray(m_es[l]), bo.canonical_edges(es[l].numpy())), (backend, l)
+    _, o_ids = bo.build_hierarchy(fe, 3, pos.shape[0], pos)
+    for mine, ref in zip(o_ids, ids):
+        assert np.array_equal(mine, ref.numpy())
+
+
+def test_float32_and_float64_positions_really_differ(eng):
+    """The dtype matters: on a structured grid the fp64 evaluation of the same float32 coordinates keeps different
+    nodes (this is the bug the float32 entry fixes -- the fixture would not catch a builder that upcasts)."""
+    from conftest import load_golden
+    z = load_golden("graphs_f32")
+    differ = 0
+    for name, kind in F32_CASES[:4]:
+        pos = z.np(f"{name}/pos")
+        fe = eng.to_flat_edge(z.np(f"{name}/cells"), kind)
+        a = eng.BistrideMultiLayerGraph(fe, 3, pos.shape[0], pos).m_ids
+        b = eng.BistrideMultiLayerGraph(fe, 3, pos.shape[0], pos.astype(np.float64)).m_ids
+        differ += any(x.shape != y.shape or not np.array_equal(x, y) for x, y in zip(a, b))
+    assert differ >= 1

@@ -1,5 +1,6 @@
-"""CPU: the host data path (bsms_gnn_amd.datapipe).  The reference datapipe cannot be imported here (h5py,
-torchdata, PyG absent), so these are self-consistency checks of the restated semantics (parity unpinned)."""
+"""CPU: the host data path (bsms_gnn_amd.datapipe) against golden vectors recorded from the reference's own datapipes
+(datasets/base.py, airfoil.py, cylinder_flow.py; tests/golden/make_golden_r2.py -> tests/golden/datapipe.npz), plus
+self-consistency checks of the cache format and the loaders."""
 import pickle
 from types import SimpleNamespace
 
@@ -90,3 +91,57 @@ def test_loaders_feed_the_model_layouts(dp):
     assert int(levels[0].face.max()) < 95 and levels[1].num_nodes == levels[0].face.numel()
     roll = next(iter(dp.TrajectoryDataset(c_con, [same], mode="rollout")))
     assert roll[0].shape == (2, 50, 6) and roll[1].shape == (2, 50, 3)       # whole trajectory, no noise
+
+
+# ------------------------------------------------------------------------- pinned against the reference datapipes
+def _golden_traj(z, name):
+    return {k: z.np(f"in/{name}/{k}") for k in ("cells", "mesh_pos", "node_type", "velocity", "density")}
+
+
+@pytest.mark.parametrize("tag,mode", [("air_train", "train"), ("air_val", "val")])
+def test_consistent_mesh_yields_match_reference(dp, tag, mode):
+    """airfoilDataPipe, consistent mesh: packed fields, mask, seeded noise (train) and the frame order (the reference
+    shuffles frames in EVERY mode) are bit-equal to what the reference yields (datasets/base.py:238-273,300-323)."""
+    from conftest import load_golden
+    z = load_golden("datapipe")
+    ds = dp.TrajectoryDataset(cfg(True, gamma=0.8), [_golden_traj(z, "trajA")], dataset="airfoil", mode=mode,
+                              seed=int(z.np(f"{tag}/seed")))
+    items = list(ds)
+    assert len(items) == int(z.np(f"{tag}/n")) == 3
+    es, ids = z.levels("air_train/mesh")
+    for i, (x, y, m, gs, mids) in enumerate(items):
+        assert x.dtype == y.dtype == torch.float32
+        assert torch.equal(x, z.t(f"{tag}/{i}/x")) and torch.equal(y, z.t(f"{tag}/{i}/y")) and torch.equal(m, z.t(f"{tag}/{i}/mask"))
+        assert all(torch.equal(a, b) for a, b in zip(mids, ids)) and torch.equal(gs[0], es[0])
+        assert all(set(map(tuple, a.T.tolist())) == set(map(tuple, b.T.tolist())) for a, b in zip(gs[1:], es[1:]))
+
+
+def test_rollout_yield_matches_reference(dp):
+    from conftest import load_golden
+    z = load_golden("datapipe")
+    (x, y, m, gs, ids), = list(dp.TrajectoryDataset(cfg(True, gamma=0.8), [_golden_traj(z, "trajA")], mode="rollout", seed=1))
+    assert torch.equal(x, z.t("air_roll/x")) and torch.equal(y, z.t("air_roll/y")) and torch.equal(m, z.t("air_roll/mask"))
+
+
+def test_variable_mesh_yields_match_reference(dp):
+    """cylinderDataPipe, consist_mesh: false: trajectory order, frame order, noise and the per-level Data lists
+    (num_nodes of level l = len(m_ids[l-1]); `face` carries m_ids and is absent on the last level, base.py:325-349)."""
+    from conftest import load_golden
+    z = load_golden("datapipe")
+    files = [str(f) for f in z.np("cyl_train/files")]
+    ds = dp.TrajectoryDataset(cfg(False, gamma=1.0), [_golden_traj(z, f) for f in files], dataset="cylinder_flow",
+                              mode="train", seed=int(z.np("cyl_train/seed")))
+    items = list(ds)
+    assert len(items) == int(z.np("cyl_train/n")) == 5
+    for i, levels in enumerate(items):
+        assert len(levels) == int(z.np(f"cyl_train/{i}/n_levels"))
+        assert torch.equal(levels[0].x, z.t(f"cyl_train/{i}/x")) and torch.equal(levels[0].y, z.t(f"cyl_train/{i}/y"))
+        assert torch.equal(levels[0].mask, z.t(f"cyl_train/{i}/mask"))
+        assert torch.equal(levels[0].edge_index, z.t(f"cyl_train/{i}/0/edge_index"))
+        for l, d in enumerate(levels):
+            assert d.num_nodes == int(z.np(f"cyl_train/{i}/{l}/num_nodes"))
+            assert (d.face is not None) == bool(z.np(f"cyl_train/{i}/{l}/has_face"))
+            if d.face is not None:
+                assert torch.equal(d.face, z.t(f"cyl_train/{i}/{l}/face"))
+            ref_e = z.np(f"cyl_train/{i}/{l}/edge_index")
+            assert set(map(tuple, d.edge_index.numpy().T.tolist())) == set(map(tuple, ref_e.T.tolist()))

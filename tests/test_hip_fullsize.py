@@ -1,0 +1,163 @@
+"""Full-size GPU parity: every BASELINE.json configuration, one whole training step (BSMS_Simulator forward +
+masked RMSE + backward, reference: src/ops/BSMS.py:39-104, src/models/model.py:127-164, src/trainer/trainer.py:96-97)
+on the HIP engine against the CPU oracle with identical seeded weights and inputs.
+
+  airfoil   5233 nodes, 5 levels, D=128, B=8, consistent mesh           (configs[2]/[3]; the bench workload)
+  cylinder  1885 nodes, 4 levels, D=128, B=8, consistent mesh           (configs[1])
+  cylinder  the same as 8 DIFFERENT meshes in one block-diagonal batch  (configs[1], the reference's cylinder layout)
+  surface   16384 nodes, 6 levels, D=256, pos_dim=3, B=2                (configs[4], per-GPU share of B=16 over 8 GPUs)
+
+Tolerances (BASELINE.json north_star: 1e-5 relative fp32)
+  * prediction: element-wise |gpu - cpu| <= 1e-5 |cpu| + 1e-5 * rms(cpu)   and   max|gpu - cpu| <= 1e-5 max|cpu|
+  * loss: |gpu - cpu| <= 1e-5 |cpu|
+  * gradients: THREE-WAY against an fp64 run of the same oracle ("exact").  At these sizes the reference's OWN fp32
+    arithmetic is 1e-5 .. 1e-4 away from the exact gradient in most parameter tensors (measured: airfoil worst 9.2e-5,
+    73 of 192 tensors above 1e-5) -- a step has ~5e8 ReLU inputs, a few dozen of which lie within fp32 round-off of 0,
+    and which side of the kink they land on differs between ANY two fp32 summation orders -- so "GPU within 1e-5 of
+    CPU fp32" is not a property even two runs of the reference on different BLAS builds have.  What is required:
+        e_gpu(p) = max|g_gpu - g_64| / max|g_64| ,  e_cpu(p) likewise for the fp32 oracle
+        (a) worst tensor:   max_p e_gpu <= max(1e-5, 2 * max_p e_cpu)
+        (b) typical tensor: median_p e_gpu <= max(1e-5, 1.5 * median_p e_cpu)
+        (c) at most 10 % of the tensors have e_gpu > max(1e-5, 2 * e_cpu(p))
+    i.e. the engine is as close to the exact gradient as the reference's fp32 path is.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bsms_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+def _to(obj, fn):
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to(o, fn) for o in obj)
+    return fn(obj)
+
+
+def _f64(t):
+    return t.double() if t.is_floating_point() else t
+
+
+def _oracle_step(sim, data, consistent):
+    sim.zero_grad(set_to_none=True)
+    pred = sim(data, consistent, False)
+    loss = ro.masked_rmse(pred, data[1], data[2])
+    loss.backward()
+    return pred.detach(), float(loss.detach()), {k: p.grad.clone() for k, p in sim.named_parameters() if p.grad is not None}
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300))
+
+
+def run_config(eng, kind, batch, layout, mesh=None, cfg=None):
+    from bench import build_blockdiag_workload, build_workload, data_tuple, make_cfg, usable_cpus
+    torch.set_num_threads(max(1, min(32, usable_cpus())))
+    if layout == "dense":
+        wl = build_workload(kind, batch, "cpu", mesh=mesh, cfg=cfg)
+        cpu_data, consistent = data_tuple(wl), True
+        gpu_data = _to(cpu_data, lambda t: t.cuda())
+    else:
+        wl = build_blockdiag_workload(kind, batch, "cpu")
+        lv = wl["data"]
+        cpu_data = (lv[0].x.unsqueeze(0), lv[0].y.unsqueeze(0), lv[0].mask.unsqueeze(0), [d.edge_index for d in lv],
+                    [d.face for d in lv[:-1]])
+        consistent = False
+        gpu_data = [d.to("cuda") for d in lv]
+    cfg = make_cfg(wl["cfg"])
+    torch.manual_seed(0)
+    ref32 = ro.BSMS_Simulator(cfg)
+    ref32(cpu_data, consistent, True)                      # one normaliser accumulation (fp64 statistics)
+    ref64 = ro.BSMS_Simulator(cfg, dtype=torch.float64)
+    ref64.load_state_dict(ref32.state_dict())
+    ref64.double()
+    mine = eng.BSMS_Simulator(cfg)
+    mine.load_state_dict(ref32.state_dict())
+    mine = mine.cuda()
+
+    t0 = time.perf_counter()
+    pred32, loss32, g32 = _oracle_step(ref32, cpu_data, consistent)
+    t32 = time.perf_counter() - t0
+    _, loss64, g64 = _oracle_step(ref64, _to(cpu_data, _f64), consistent)
+    t64 = time.perf_counter() - t0 - t32
+
+    pred = mine(gpu_data, consistent, False)
+    tar, mask = (gpu_data[1], gpu_data[2]) if consistent else (gpu_data[0].y.unsqueeze(0), gpu_data[0].mask.unsqueeze(0))
+    loss = eng.masked_rmse(pred, tar, mask)
+    loss.backward()
+    torch.cuda.synchronize()
+    gg = {k: p.grad.detach().cpu() for k, p in mine.named_parameters() if p.grad is not None}
+    return dict(pred=pred.detach().cpu(), pred32=pred32, loss=float(loss.detach()), loss32=loss32, loss64=loss64,
+                gg=gg, g32=g32, g64=g64, t32=t32, t64=t64, levels=wl["levels"])
+
+
+def check(r, tag):
+    # ---- forward: element-wise and max-norm, against the fp32 oracle
+    a, b = r["pred"].double(), r["pred32"].double()
+    scale, rms = float(b.abs().max()), float(b.pow(2).mean().sqrt())
+    diff = (a - b).abs()
+    assert float(diff.max()) <= 1e-5 * scale, (tag, "pred max-norm", float(diff.max()) / scale)
+    bad = diff > 1e-5 * b.abs() + 1e-5 * rms
+    assert not bool(bad.any()), (tag, "pred element-wise", int(bad.sum()))
+    assert abs(r["loss"] - r["loss32"]) <= 1e-5 * abs(r["loss32"]), (tag, r["loss"], r["loss32"])
+    # ---- gradients: three-way against fp64 (criterion in the module docstring)
+    assert set(r["gg"]) == set(r["g32"]) == set(r["g64"]), "a parameter is missing its gradient"
+    keys = sorted(r["g64"])
+    e_gpu = np.array([_rel(r["gg"][k], r["g64"][k]) for k in keys])
+    e_cpu = np.array([_rel(r["g32"][k], r["g64"][k]) for k in keys])
+    direct = np.array([_rel(r["gg"][k], r["g32"][k]) for k in keys])
+    worst = int(np.argmax(e_gpu))
+    over = (e_gpu > np.maximum(1e-5, 2 * e_cpu))
+    print(f"\n[{tag}] levels {r['levels']}\n  oracle fp32 {r['t32']:.1f} s, fp64 {r['t64']:.1f} s; loss gpu {r['loss']:.7f} "
+          f"cpu32 {r['loss32']:.7f} f64 {r['loss64']:.7f}; pred max-norm {float(diff.max()) / scale:.2e}\n"
+          f"  grads vs fp64 over {len(keys)} tensors: gpu worst {e_gpu.max():.2e} ({keys[worst]}) median {np.median(e_gpu):.2e} | "
+          f"cpu32 worst {e_cpu.max():.2e} median {np.median(e_cpu):.2e} | gpu-vs-cpu32 worst {direct.max():.2e} "
+          f"median {np.median(direct):.2e} | tensors over: {int(over.sum())}")
+    assert e_gpu.max() <= max(1e-5, 2 * e_cpu.max()), (tag, "worst tensor", keys[worst], e_gpu.max(), e_cpu.max())
+    assert np.median(e_gpu) <= max(1e-5, 1.5 * np.median(e_cpu)), (tag, "median", np.median(e_gpu), np.median(e_cpu))
+    assert over.sum() <= 0.10 * len(keys), (tag, "tensors over", [keys[i] for i in np.flatnonzero(over)][:8])
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import bsms_gnn_amd as eng
+    return eng
+
+
+def test_airfoil_b8_step_matches_oracle(eng):
+    r = run_config(eng, "airfoil", 8, "dense")
+    assert r["levels"][0] == (5233, 31354) and len(r["levels"]) == 6
+    check(r, "airfoil B=8 L=5 D=128")
+
+
+def test_cylinder_b8_dense_step_matches_oracle(eng):
+    r = run_config(eng, "cylinder", 8, "dense")
+    assert r["levels"][0] == (1885, 11264) and len(r["levels"]) == 5
+    check(r, "cylinder B=8 L=4 D=128 dense")
+
+
+def test_cylinder_b8_blockdiag_step_matches_oracle(eng):
+    r = run_config(eng, "cylinder", 8, "blockdiag")
+    assert r["levels"][0][0] == 8 * 1885 and len(r["levels"]) == 5
+    check(r, "cylinder 8 different meshes, block-diagonal")
+
+
+def test_surface_b2_step_matches_oracle(eng):
+    r = run_config(eng, "surface", 2, "dense")
+    assert r["levels"][0][0] == 16384 and len(r["levels"]) == 7 and r["levels"][-1][0] >= 2
+    check(r, "surface B=2 L=6 D=256 p=3")
+
+
+def test_airfoil_depth7_reference_default(eng):
+    """configs/model/airfoil.yaml:4 `unet_depth: 7` (the reference's default) on an airfoil-sized mesh that supports
+    it (bench.strip_mesh: 5232 nodes, 32 at level 7): one B=2 step matches the oracle, same rules."""
+    from bench import strip_mesh
+    w, mesh = strip_mesh(327, 16, 7)
+    r = run_config(eng, "airfoil", 2, "dense", mesh=mesh, cfg=w)
+    assert len(r["levels"]) == 8 and r["levels"][0][0] == 5232 and r["levels"][-1][0] >= 2
+    check(r, "airfoil-sized strip B=2 L=7 (reference default depth)")
