@@ -5,7 +5,9 @@
 //   up    i = 0..L-1 :  d = L-1-i ;  u_d = prolong_d(h) ;  h = GMP_up[i](u_d, pos_d) + s_d
 //
 // restrict = WeightedEdgeConv + index by m_ids fused, prolong = Unpool + WeightedEdgeConv(aggragating=False) fused
-// (bsms_edge_conv with `pooled`).  The entry only sequences the block / transition entries of this library on the
+// (bsms_edge_conv with `pooled`).  The skip additions are fused: forward into the up block's node-chain epilogue,
+// backward into the adjoint of the restriction (same additions in the same order as separate elementwise passes).
+// The entry only sequences the block / transition kernels of this library on the
 // caller's stream -- no new arithmetic -- so that a training step costs the host two calls instead of ~60 autograd
 // nodes (the Python mirror of the reference's module tree needed 5.4 ms per step to enqueue what the GPU runs in
 // 7.6 ms at airfoil size and was the limit outright at cylinder size).
@@ -64,8 +66,11 @@ Saved carve_saved(void* base, const Shape& s, bool training) {
 
 struct Work {
   void* gmp;                      // scratch of one block call (largest level)
+  void* gmp_b;                    // second scratch set: the backward alternates so that block k's weight gradients (side
+                                  // lanes) can still be reading set k & 1 while block k+1 runs in the other
   float* skip[kMaxLevels];        // fwd: outputs of the down blocks; bwd: gradient arriving at the skip connections
   float* a[2];                    // two ping-pong level-0 sized buffers
+  void* packs[2 * kMaxLevels + 1];  // inference: weight packs of every block (training keeps them in the saved blobs)
   size_t bytes;
 };
 Work carve_work(void* base, const Shape& s) {
@@ -74,11 +79,14 @@ Work carve_work(void* base, const Shape& s) {
   size_t g = 0;
   for (int i = 0; i <= s.L; ++i) g = std::max(g, bsms_gmp_work_bytes(s.B, s.N[i], s.E[i], s.D, s.H));
   w.gmp = c.bytes(g);
+  w.gmp_b = c.bytes(s.L > 0 ? g : 0);
   for (int i = 0; i < s.L; ++i) w.skip[i] = c.floats(size_t(s.B) * s.N[i] * s.D);
   for (int k = 0; k < 2; ++k) w.a[k] = c.floats(size_t(s.B) * s.N[0] * s.D);
+  for (int k = 0; k <= 2 * s.L; ++k) w.packs[k] = c.bytes(gmp_pack_bytes(s.D, s.H));
   w.bytes = c.off;
   return w;
 }
+inline int level_of_block(int k, int L) { return k <= L ? k : 2 * L - k; }   // down 0..L-1, bottom L, up i acts on L-1-i
 
 int make_shape(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int H, Shape* s, const char* who) {
   BSMS_REQUIRE(plans != nullptr && L >= 0 && L <= kMaxLevels, BSMS_E_INVALID_ARG, "%s: unet_depth %d (0..%d)", who, L, kMaxLevels);
@@ -91,21 +99,6 @@ int make_shape(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int
       BSMS_REQUIRE(plans[i - 1]->Nk == s->N[i], BSMS_E_SHAPE, "%s: level %d keeps %lld nodes but level %d has %lld", who, i - 1,
                    (long long)plans[i - 1]->Nk, i, (long long)s->N[i]);
   }
-  return BSMS_OK;
-}
-
-__global__ __launch_bounds__(256) void k_add_rows(const float4* a, const float4* b, float4* out, int64_t n4) {
-  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += int64_t(gridDim.x) * 256) {
-    const float4 x = a[i], y = b[i];
-    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-  }
-}
-int add_rows(const float* a, const float* b, float* out, int64_t n, hipStream_t s) {  // n % 4 == 0 (D is a multiple of 32)
-  if (n == 0) return BSMS_OK;
-  const int64_t n4 = n / 4;
-  hipLaunchKernelGGL(k_add_rows, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0, s,
-                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n4);
-  BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
 
@@ -140,12 +133,15 @@ extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* cons
   Saved v = training ? carve_saved(saved, s, true) : carve_saved(reinterpret_cast<char*>(work) + w.bytes, s, false);
   const int64_t posB = pos_batch_stride ? B : 1;   // a 2-D pos is shared by the batch (ops/basic.py:87-88)
 
-  // Positions of all coarse levels first, on a side stream: they depend on pos and ew only (ops/BSMS.py:75,85-88)
-  // and are five latency-bound launches that would otherwise sit between the blocks; joined before level 1 needs them.
+  // Two side lanes run ahead of the blocks; both are joined before level 1 starts:
+  //  lane 1: positions of all coarse levels -- they depend on pos and ew only (ops/BSMS.py:75,85-88);
+  //  lane 0: the weight prepacks of blocks 1..2L (block 0's stays in front of block 0 on the caller's stream): the
+  //          weights are fixed for the whole call, so none of these small launches has to sit between two blocks.
   const float* pos_l[kMaxLevels + 1];
   int64_t pstride_l[kMaxLevels + 1];
   pos_l[0] = pos; pstride_l[0] = pos_batch_stride;
-  SideLane* lane = nullptr;
+  SideLane *lane = nullptr, *lane0 = nullptr;
+  auto packs_of = [&](int k) { return training ? nullptr : w.packs[k]; };
   if (L > 0) {
     if ((rc = side_lane(&lane, 1)) || (rc = side_fork(lane, st))) return rc;
     for (int i = 0; i < L; ++i) {
@@ -153,11 +149,17 @@ extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* cons
       pos_l[i + 1] = v.pos[i + 1];
       pstride_l[i + 1] = pos_batch_stride ? s.N[i + 1] * p : 0;
     }
+    if ((rc = side_lane(&lane0, 0)) || (rc = side_fork(lane0, st))) return rc;
+    for (int k = 1; k <= 2 * L; ++k) {
+      const int lv = level_of_block(k, L);
+      if ((rc = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream))) return rc;
+    }
   }
   const float* hi = h;
   for (int i = 0; i < L; ++i) {
-    if ((rc = bsms_gmp_fwd(plans[i], hi, pos_l[i], B, D, p, pstride_l[i], hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp, stream))) return rc;
-    if (i == 0 && (rc = side_join(lane, st))) return rc;
+    if ((rc = gmp_fwd_core(plans[i], hi, pos_l[i], B, D, p, pstride_l[i], hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp,
+                           packs_of(i), i == 0, nullptr, st))) return rc;
+    if (i == 0 && ((rc = side_join(lane, st)) || (rc = side_join(lane0, st)))) return rc;
     // restrict the features to the kept nodes (ops/BSMS.py:74, 79-83)
     if ((rc = bsms_edge_conv(plans[i], w.skip[i], B, D, ew[i], 1, 1, v.hin[i + 1], stream))) return rc;
     hi = v.hin[i + 1];
@@ -165,15 +167,15 @@ extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* cons
   const float* pi = pos_l[L];
   const int64_t pstride = pstride_l[L];
   float* cur = (L == 0) ? out : w.a[0];
-  if ((rc = bsms_gmp_fwd(plans[L], hi, pi, B, D, p, pstride, hidden, block(params, L, hidden), cur, v.gmp[L], w.gmp, stream))) return rc;
+  if ((rc = gmp_fwd_core(plans[L], hi, pi, B, D, p, pstride, hidden, block(params, L, hidden), cur, v.gmp[L], w.gmp, packs_of(L),
+                         L == 0, nullptr, st))) return rc;
   for (int i = 0; i < L; ++i) {
     const int d = L - 1 - i;
     if ((rc = bsms_edge_conv(plans[d], cur, B, D, ew[d], 0, 1, v.upin[d], stream))) return rc;   // prolong (BSMS.py:98-100)
-    float* tmp = w.a[(i + 1) & 1];
-    if ((rc = bsms_gmp_fwd(plans[d], v.upin[d], pos_l[d], B, D, p, pstride_l[d], hidden, block(params, L + 1 + i, hidden), tmp,
-                           v.gmp[L + 1 + i], w.gmp, stream))) return rc;
-    float* nxt = (d == 0) ? out : w.a[i & 1];
-    if ((rc = add_rows(tmp, w.skip[d], nxt, B * s.N[d] * D, st))) return rc;                      // skip connection (BSMS.py:102)
+    // up block + skip connection (BSMS.py:101-102): the node chain's epilogue adds s_d after its own residual
+    float* nxt = (d == 0) ? out : w.a[(i + 1) & 1];
+    if ((rc = gmp_fwd_core(plans[d], v.upin[d], pos_l[d], B, D, p, pstride_l[d], hidden, block(params, L + 1 + i, hidden), nxt,
+                           v.gmp[L + 1 + i], w.gmp, packs_of(L + 1 + i), false, w.skip[d], st))) return rc;
     cur = nxt;
   }
   return BSMS_OK;
@@ -199,6 +201,22 @@ extern "C" int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* cons
     pstride_l[i] = i ? (pos_batch_stride ? s.N[i] * p : 0) : pos_batch_stride;
     hin_l[i] = i ? v.hin[i] : h;
   }
+  // Blocks run in reverse order.  The side lanes of a block (its weight gradients, csrc/gmp.hip) are NOT joined at the
+  // end of the block: block k only marks them (slot k & 1) and the caller's stream goes straight on to block k+1, which
+  // works in the other scratch set; block k+2 waits for slot k & 1 before it overwrites that set.  Measured before
+  // this change the caller's stream idled 30-160 us per block at the join (the split-K weight gradients of a block
+  // take longer than its gradient strand), ~1 ms of a 7.6 ms step.
+  SideLane *lane0 = nullptr, *lane1 = nullptr;
+  if ((rc = side_lane(&lane0, 0)) || (rc = side_lane(&lane1, 1))) return rc;
+  int nblk = 0;
+  auto run_block = [&](int level, const float* x, const float* g_in, int k, float* gx) -> int {
+    const int slot = nblk & 1;
+    int r;
+    if (nblk >= 2 && ((r = side_wait_mark(lane0, slot, st)) || (r = side_wait_mark(lane1, slot, st)))) return r;
+    ++nblk;
+    return gmp_bwd_core(plans[level], x, pos_l[level], g_in, B, D, p, pstride_l[level], hidden, block(params, k, hidden), v.gmp[k],
+                        slot ? w.gmp_b : w.gmp, gx, block(grads, k, hidden), slot, st);
+  };
   // up path, last block first.  The gradient reaching level d is both the up block's grad_out and the gradient of
   // the skip connection s_d: it stays in w.skip[d] until the down path picks it up.
   const float* g = grad_out;
@@ -207,8 +225,7 @@ extern "C" int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* cons
     const int d = L - 1 - i;
     skip_grad[d] = g;      // level 0: the caller's grad_out; deeper: w.skip[d], written by the level above
     float* gu = w.a[0];    // gradient w.r.t. the up block's input u_d
-    if ((rc = bsms_gmp_bwd(plans[d], v.upin[d], pos_l[d], g, B, D, p, pstride_l[d], hidden, block(params, L + 1 + i, hidden),
-                           v.gmp[L + 1 + i], w.gmp, gu, block(grads, L + 1 + i, hidden), stream))) return rc;
+    if ((rc = run_block(d, v.upin[d], g, L + 1 + i, gu))) return rc;
     // adjoint of prolong_d: a restrict-shaped gather onto level d + 1, kept for that level's skip connection
     float* gnext = (d + 1 < L) ? w.skip[d + 1] : w.a[1];
     if ((rc = bsms_edge_conv(plans[d], gu, B, D, ew[d], 1, 1, gnext, stream))) return rc;
@@ -216,18 +233,18 @@ extern "C" int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* cons
   }
   // bottom block
   float* gb = w.a[0];
-  if ((rc = bsms_gmp_bwd(plans[L], hin_l[L], pos_l[L], g, B, D, p, pstride_l[L], hidden, block(params, L, hidden), v.gmp[L], w.gmp,
-                         (L == 0) ? grad_h : gb, block(grads, L, hidden), stream))) return rc;
+  if ((rc = run_block(L, hin_l[L], g, L, (L == 0) ? grad_h : gb))) return rc;
   const float* gl = gb;
   for (int i = L - 1; i >= 0; --i) {
-    // adjoint of restrict_i, plus the gradient that arrived at the skip connection of level i
+    // adjoint of restrict_i, plus the gradient that arrived at the skip connection of level i (fused add)
     float* gs = w.a[1];
-    if ((rc = bsms_edge_conv(plans[i], gl, B, D, ew[i], 0, 1, gs, stream))) return rc;
-    if ((rc = add_rows(gs, skip_grad[i], gs, B * s.N[i] * D, st))) return rc;
+    if ((rc = edge_conv_add(plans[i], gl, B, D, ew[i], 0, 1, gs, skip_grad[i], st))) return rc;
     float* gx = (i == 0) ? grad_h : w.a[0];
-    if ((rc = bsms_gmp_bwd(plans[i], hin_l[i], pos_l[i], gs, B, D, p, pstride_l[i], hidden, block(params, i, hidden), v.gmp[i], w.gmp,
-                           gx, block(grads, i, hidden), stream))) return rc;
+    if ((rc = run_block(i, hin_l[i], gs, i, gx))) return rc;
     gl = gx;
   }
+  // every weight gradient has to be complete when the call returns
+  for (int slot = 0; slot < 2; ++slot)
+    if ((rc = side_wait_mark(lane0, slot, st)) || (rc = side_wait_mark(lane1, slot, st))) return rc;
   return BSMS_OK;
 }

@@ -40,6 +40,8 @@ constexpr int kChunkHdrFloats = 256;                     // 1 KB chunk header (b
 // the backward chain masks gradients from 16 bytes per row instead of re-reading 4 D bytes.
 constexpr size_t mask_words_per_row(int64_t D) { return size_t(4) * (D <= 128 ? 1 : D / 128); }
 constexpr size_t act_floats(size_t rows, int64_t D) { return rows * size_t(D) + rows * mask_words_per_row(D); }
+// row pitch (floats) of the saved fiber tensor: p + 1 values padded to one or two 16-byte pieces
+constexpr int fiber_ld(int64_t p) { return p + 1 <= 4 ? 4 : 8; }
 // floats in one weight pack of a D x D Linear (bf16 x 3 planes + headers)
 constexpr size_t pack_floats(int64_t D) { return size_t(D / 32) * (kChunkHdrFloats + size_t(D / 16) * 768); }
 
@@ -64,6 +66,8 @@ struct ChainFwdArgs {
   const float* pos;          // IN_EDGE
   int64_t pos_bstride;
   int p;
+  float* fiber_out;          // IN_EDGE: [R, fiber_ld(p)] the fiber [pos_i - pos_j, |pos_i - pos_j|, 0...] of every edge row, kept
+                             // for the backward's narrow weight gradient (nullable)
   // ---- MFMA stages
   int nstage;
   const float4* wp[kMaxStages];  // packs (the Linear's bias travels in the pack header, see PackDesc)
@@ -75,6 +79,7 @@ struct ChainFwdArgs {
   float* yln;         // OUT_LN: normalised output before the residual (nullable)
   float* rstd;        // OUT_LN: [R] (nullable)
   const float* resid; // OUT_LN: residual rows added to y (nullable)
+  const float* resid2; // OUT_LN: second residual (the U-Net skip connection, ops/BSMS.py:102), added after `resid` (nullable)
   int accumulate;     // OUT_PLAIN: y += result
   const float* wout;  // OUT_SMALL: [C][D]
   const float* bout;  // OUT_SMALL: [C]
@@ -149,8 +154,9 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
 // small-side weight gradients: out[s*os + f*of] = sum_r G[r][f] * S[r][s],  s < S (<= 8)
 struct SmallWgradArgs {
   const float* G;  // [R,D]
-  const float* S;  // [R,S] (null when fiber mode)
+  const float* S;  // [R,S_ld] narrow matrix, S_cols <= S_ld columns used (null when fiber mode)
   int S_cols;
+  int S_ld;        // row pitch of S (0 = S_cols)
   // fiber mode: S[r] = [pos_i - pos_j, |pos_i - pos_j|] recomputed from the plan (edge layer 0)
   const int32_t *src, *dst;
   int32_t E, N;

@@ -453,8 +453,19 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
           n2 = fmaf(rel, rel, n2);
           axpy_features<NB>(act, w0t + c * D, rel, lg);
         }
-      axpy_features<NB>(act, w0t + a.p * D, sqrtf(n2), lg);
+      const float nrm = sqrtf(n2);
+      axpy_features<NB>(act, w0t + a.p * D, nrm, lg);
       relu_into<NB>(act, act);
+      if (a.fiber_out && live && lg == 0) {   // one lane per row keeps the fiber for the backward (16 or 32 bytes per edge)
+        float f[8];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) f[c] = c < a.p ? pi[c] - pj[c] : (c == a.p ? nrm : 0.f);
+        f[7] = a.p == 7 ? nrm : 0.f;
+        const int ld = fiber_ld(a.p);
+        float4* dst = reinterpret_cast<float4*>(a.fiber_out + row * ld);
+        dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+        if (ld == 8) dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+      }
     }
   }
 
@@ -517,6 +528,11 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     if (a.rstd && lg == 0) a.rstd[row] = rstd;
     if (a.resid) {
       load_rows<NB>(act, a.resid + row * D, lg);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) acc[t] += act[t];
+    }
+    if (a.resid2) {   // (LN + x) + skip: the same two additions, in the same order, as GMP's `+ x` then BSGMP's `h + down_outs`
+      load_rows<NB>(act, a.resid2 + row * D, lg);
 #pragma unroll
       for (int t = 0; t < NB; ++t) acc[t] += act[t];
     }
@@ -736,6 +752,7 @@ int launch_bwd_n(int gin, int first, const ChainBwdArgs& a, hipStream_t s) {
 }  // namespace
 
 // experiments only (not in bsms_hip.h): what residency does the runtime compute for the D = 128 edge chains?
+#ifdef BSMS_EXPERIMENTS
 extern "C" int bsms_debug_occupancy(int* fwd_blocks_per_cu, int* bwd_blocks_per_cu) {
   hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(fwd_blocks_per_cu, k_chain_fwd<8, IN_EDGE, OUT_LN>,
                                                                 kChainThreads, Ring<8>::lds_bytes);
@@ -743,6 +760,7 @@ extern "C" int bsms_debug_occupancy(int* fwd_blocks_per_cu, int* bwd_blocks_per_
                                                                 kChainThreads, Ring<8>::lds_bytes);
   return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -4;
 }
+#endif
 
 namespace bsms {
 

@@ -44,12 +44,38 @@ inline hipStream_t as_stream(bsms_stream_t s) { return reinterpret_cast<hipStrea
 struct SideLane {
   hipStream_t stream = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  hipEvent_t done_ev[2] = {nullptr, nullptr};   // "everything queued on the lane up to here has run", two slots
+  bool marked[2] = {false, false};
 };
 constexpr int kSideLanes = 2;
 int side_lane(SideLane** out, int which = 0);        // for the current device; `which` < kSideLanes
 int side_fork(SideLane* lane, hipStream_t main);     // side waits for main
 int side_join(SideLane* lane, hipStream_t main);     // main waits for side
+// Deferred join: side_mark records "the lane's work so far" into slot 0/1; side_wait_mark makes `main` wait for what
+// that slot recorded last (no-op if never marked).  The U-Net backward lets the weight gradients of block k run
+// under the gradient chain of block k+1 and only waits for them before block k+2 reuses their scratch (bsgmp.hip).
+int side_mark(SideLane* lane, int slot);
+int side_wait_mark(SideLane* lane, int slot, hipStream_t main);
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- internal entry points shared between translation units (not part of the C ABI)
+// rowsum.hip: bsms_edge_conv + fused addend
+int edge_conv_add(const bsms_plan* p, const float* x, int64_t B, int64_t D, const float* ew, int aggregating, int pooled,
+                  float* out, const float* addend, hipStream_t stream);
+// gmp.hip: the GMP block with the knobs the U-Net entry uses.  `packs_base` (nullable): where the weight packs of an
+// INFERENCE call live (training keeps them in `saved`); `do_prepack` = false: the packs were filled by gmp_prepack
+// earlier in the same step; `resid2` (nullable): the skip connection added to the block's output (ops/BSMS.py:102).
+size_t gmp_pack_bytes(int64_t D, int hidden);
+int gmp_prepack(int64_t B, int64_t N, int64_t E, int64_t D, int64_t p, int hidden, const float* const* params,
+                void* saved, void* work, void* packs_base, hipStream_t stream);
+int gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
+                 int64_t pos_bstride, int hidden, const float* const* params, float* out, void* saved, void* work,
+                 void* packs_base, bool do_prepack, const float* resid2, hipStream_t stream);
+// `defer_slot` < 0: the side lanes are joined before returning (ABI semantics).  0/1: they are only MARKED in that slot;
+// the caller joins later with side_wait_mark on both lanes and must not touch `work` or read `grads` before that.
+int gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, const float* grad_out, int64_t B, int64_t D,
+                 int64_t p, int64_t pos_bstride, int hidden, const float* const* params, const void* saved, void* work,
+                 float* grad_x, float* const* grads, int defer_slot, hipStream_t stream);
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 }  // namespace bsms

@@ -37,9 +37,18 @@ struct Carver {  // identical walk for size queries (base == nullptr) and real b
 
 bool supported_D(int64_t D) { return D == 32 || D == 64 || D == 128 || D == 256; }
 
+// Experiment switches exist only in a library built with -DBSMS_EXPERIMENTS (BSMS_EXPERIMENTS=1 python
+// bsms-gnn_amd/build.py; used by profiles/experiments.py, tile_timeline.py, ab.sh): the production build has no
+// environment variable or exported setter that could change kernel behaviour (bit 0 skips the activation stores the
+// backward needs).
+#ifdef BSMS_EXPERIMENTS
 static int env_flags() { const char* e = getenv("BSMS_DEBUG_FLAGS"); return e ? atoi(e) : 0; }
 unsigned long long* g_timing = nullptr;
-int g_debug_flags = env_flags();  // experiments only: bit0 skip fwd activation stores, bit1 plain (not nt) stores, bit2 nt final y
+int g_debug_flags = env_flags();  // bit0 skip fwd activation stores, bit1 plain (not nt) stores, bit2 nt final y, bit3 no side lanes, ...
+#else
+constexpr unsigned long long* g_timing = nullptr;
+constexpr int g_debug_flags = 0;
+#endif
 
 void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, int K, int kind, float* dst,
               const float* bias = nullptr) {
@@ -49,7 +58,7 @@ void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, i
 
 // ================================================================================== GMP layout
 struct GmpSaved {
-  float *e_act[kMaxStages], *e_y, *e_rstd, *aggr;
+  float *e_act[kMaxStages], *e_y, *e_rstd, *aggr, *e_fiber;
   float *n_act[kMaxStages], *n_yln, *n_rstd;
   // packs (fragment order)
   float *e_wi, *e_wj, *e_wft, *e_w[kMaxStages], *e_wt[kMaxStages], *e_wit, *e_wjt;
@@ -58,7 +67,10 @@ struct GmpSaved {
 };
 // training = true: everything the backward needs.  training = false (inference, `saved` == NULL at the ABI):
 // only the messages, the aggregate and the forward packs, carved from the scratch buffer instead.
-GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H, bool training = true) {
+// `packs_base` (inference only, nullable): carve the weight packs from there instead of behind the messages, so that
+// they can be filled ahead of the call and survive the scratch reuse of other blocks.
+GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H, bool training = true,
+                         void* packs_base = nullptr) {
   Carver c(base);
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
@@ -66,18 +78,21 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
     for (int l = 0; l < H; ++l) s.e_act[l] = c.take(act_floats(re, D));
   s.e_y = c.take(re * D);
   if (training) s.e_rstd = c.take(re);
+  if (training) s.e_fiber = c.take(re * 8);   // [B*E, fiber_ld(p)]: sized for the widest pitch (p is not part of the size query)
   s.aggr = c.take(rn * D);
   if (training) {
     for (int l = 0; l < H; ++l) s.n_act[l] = c.take(act_floats(rn, D));
     s.n_yln = c.take(rn * D);
     s.n_rstd = c.take(rn);
   }
-  s.e_wi = c.take(dd); s.e_wj = c.take(dd); s.e_wft = c.take(size_t(8) * D);
-  if (training) { s.e_wit = c.take(dd); s.e_wjt = c.take(dd); }
-  for (int l = 1; l <= H; ++l) { s.e_w[l] = c.take(dd); if (training) s.e_wt[l] = c.take(dd); }
-  s.n_w0x = c.take(dd); s.n_w0a = c.take(dd);
-  if (training) { s.n_w0xt = c.take(dd); s.n_w0at = c.take(dd); }
-  for (int l = 1; l <= H; ++l) { s.n_w[l] = c.take(dd); if (training) s.n_wt[l] = c.take(dd); }
+  Carver cp(packs_base);
+  Carver& k = packs_base ? cp : c;
+  s.e_wi = k.take(dd); s.e_wj = k.take(dd); s.e_wft = k.take(size_t(8) * D);
+  if (training) { s.e_wit = k.take(dd); s.e_wjt = k.take(dd); }
+  for (int l = 1; l <= H; ++l) { s.e_w[l] = k.take(dd); if (training) s.e_wt[l] = k.take(dd); }
+  s.n_w0x = k.take(dd); s.n_w0a = k.take(dd);
+  if (training) { s.n_w0xt = k.take(dd); s.n_w0at = k.take(dd); }
+  for (int l = 1; l <= H; ++l) { s.n_w[l] = k.take(dd); if (training) s.n_wt[l] = k.take(dd); }
   s.bytes = c.off;
   return s;
 }
@@ -118,8 +133,10 @@ int check_gmp(const bsms_plan_t* plan, int64_t B, int64_t D, int64_t p, int H, c
 }  // namespace
 
 // =================================================================================== GMP entries
+#ifdef BSMS_EXPERIMENTS
 extern "C" void bsms_debug_set_flags(int flags) { g_debug_flags = flags; }  // not in bsms_hip.h: experiments only
 extern "C" void bsms_debug_set_timing(unsigned long long* dev_buf) { g_timing = dev_buf; }
+#endif
 
 extern "C" size_t bsms_gmp_saved_bytes(int64_t B, int64_t N, int64_t E, int64_t D, int hidden) {
   if (hidden < 1 || hidden >= kMaxStages) return 0;
@@ -130,23 +147,18 @@ extern "C" size_t bsms_gmp_work_bytes(int64_t B, int64_t N, int64_t E, int64_t D
   return carve_gmp_work(nullptr, B, N, E, D, hidden).bytes;
 }
 
-extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
-                            int64_t pos_bstride, int H, const float* const* params, float* out, void* saved,
-                            void* work, bsms_stream_t stream) {
-  int rc = check_gmp(plan, B, D, p, H, "gmp_fwd");
-  if (rc) return rc;
-  BSMS_REQUIRE(x && pos && params && out && work, BSMS_E_INVALID_ARG, "gmp_fwd: null argument");
-  hipStream_t s = as_stream(stream);
-  const int64_t N = plan->N, E = plan->E;
+namespace {
+// where the saved tensors / packs of a forward call live (see carve_gmp_saved)
+GmpSaved locate_saved(void* saved, const GmpWork& wk, int64_t B, int64_t N, int64_t E, int64_t D, int H, void* packs_base) {
+  return saved ? carve_gmp_saved(saved, B, N, E, D, H, true)
+               : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false, packs_base);  // inference: lives in the gradient scratch
+}
+
+int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training, const float* const* params, hipStream_t s) {
   const int nl = H + 1;
   const float* const* pn = params;            // mlp_node: W_l = pn[2l], b_l = pn[2l+1]
   const float* const* pe = params + 2 * nl;   // mlp_edge
   const int ldE0 = int(2 * D + p + 1);
-  const bool training = saved != nullptr;     // saved == NULL: inference, nothing is kept for a backward
-  GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
-  GmpSaved sv = training ? carve_gmp_saved(saved, B, N, E, D, H, true)
-                         : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false);  // lives in the gradient scratch
-
   PackTable t{};
   add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG, sv.e_wi, pe[1]);
   add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG, sv.e_wj);
@@ -169,7 +181,39 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
     add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w[l], pn[2 * l + 1]);
     if (training) add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_wt[l]);
   }
-  if ((rc = launch_prepack(t, s))) return rc;
+  return launch_prepack(t, s);
+}
+}  // namespace
+
+size_t bsms::gmp_pack_bytes(int64_t D, int hidden) {   // inference packs of one block (upper bound: every take() is 256-byte aligned)
+  return (size_t(2 * hidden + 4) * (pack_floats(D) * sizeof(float) + 256)) + size_t(8) * D * sizeof(float) + 256;
+}
+
+int bsms::gmp_prepack(int64_t B, int64_t N, int64_t E, int64_t D, int64_t p, int H, const float* const* params, void* saved,
+                      void* work, void* packs_base, hipStream_t s) {
+  GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
+  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base);
+  return prepack_block(sv, D, p, H, saved != nullptr, params, s);
+}
+
+extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
+                            int64_t pos_bstride, int H, const float* const* params, float* out, void* saved,
+                            void* work, bsms_stream_t stream) {
+  return bsms::gmp_fwd_core(plan, x, pos, B, D, p, pos_bstride, H, params, out, saved, work, nullptr, true, nullptr,
+                            as_stream(stream));
+}
+
+int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
+                       int64_t pos_bstride, int H, const float* const* params, float* out, void* saved, void* work,
+                       void* packs_base, bool do_prepack, const float* resid2, hipStream_t s) {
+  int rc = check_gmp(plan, B, D, p, H, "gmp_fwd");
+  if (rc) return rc;
+  BSMS_REQUIRE(x && pos && params && out && work, BSMS_E_INVALID_ARG, "gmp_fwd: null argument");
+  const int64_t N = plan->N, E = plan->E;
+  const bool training = saved != nullptr;     // saved == NULL: inference, nothing is kept for a backward
+  GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
+  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base);
+  if (do_prepack && (rc = prepack_block(sv, D, p, H, training, params, s))) return rc;
 
   // node pre-projections
   {
@@ -185,6 +229,7 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
     a.R = B * E; a.K0 = int(p + 1); a.w0t = sv.e_wft; a.store_in = sv.e_act[0];
     a.src = plan->src; a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
     a.Ps = wk.Ps; a.Pd = wk.Pd; a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p;
+    a.fiber_out = training ? sv.e_fiber : nullptr;
     a.nstage = H;
     for (int st = 0; st < H; ++st) {
       a.wp[st] = reinterpret_cast<const float4*>(sv.e_w[st + 1]);
@@ -213,7 +258,7 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
       a.wp[st] = reinterpret_cast<const float4*>(sv.n_w[st]);
       a.store[st] = (training && st < H) ? sv.n_act[st] : nullptr;
     }
-    a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x;
+    a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x; a.resid2 = resid2;
     a.store_mode = 1;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_LN, a, s))) return rc;
   }
@@ -223,11 +268,35 @@ extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float
 extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float* pos, const float* grad_out, int64_t B,
                             int64_t D, int64_t p, int64_t pos_bstride, int H, const float* const* params,
                             const void* saved, void* work, float* grad_x, float* const* grads, bsms_stream_t stream) {
+  return bsms::gmp_bwd_core(plan, x, pos, grad_out, B, D, p, pos_bstride, H, params, saved, work, grad_x, grads, -1,
+                            as_stream(stream));
+}
+
+namespace {
+// joins (or marks) the side lanes on EVERY exit path of gmp_bwd_core: an error return between fork and join would
+// otherwise leave the lane dangling, which also breaks an in-progress HIP-graph capture
+struct LaneScope {
+  SideLane* lane = nullptr;
+  hipStream_t main;
+  int slot;
+  explicit LaneScope(hipStream_t m, int defer_slot) : main(m), slot(defer_slot) {}
+  int finish() {
+    SideLane* l = lane;
+    lane = nullptr;
+    if (!l) return BSMS_OK;
+    return slot < 0 ? side_join(l, main) : side_mark(l, slot);
+  }
+  ~LaneScope() { if (lane) side_join(lane, main); }
+};
+}  // namespace
+
+int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, const float* grad_out, int64_t B, int64_t D,
+                       int64_t p, int64_t pos_bstride, int H, const float* const* params, const void* saved, void* work,
+                       float* grad_x, float* const* grads, int defer_slot, hipStream_t s) {
   int rc = check_gmp(plan, B, D, p, H, "gmp_bwd");
   if (rc) return rc;
   BSMS_REQUIRE(x && pos && grad_out && params && saved && work && grad_x && grads, BSMS_E_INVALID_ARG,
                "gmp_bwd: null argument");
-  hipStream_t s = as_stream(stream);
   const int64_t N = plan->N, E = plan->E;
   const int nl = H + 1;
   float* const* gn = grads;
@@ -276,9 +345,11 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
   SideLane* lane = nullptr;
   const bool overlap = !(g_debug_flags & 8);
   hipStream_t ws = s;
+  LaneScope scope1(s, defer_slot), scope2(s, defer_slot);
   if (overlap) {
     if ((rc = side_lane(&lane)) || (rc = side_fork(lane, s))) return rc;
     ws = lane->stream;
+    scope1.lane = lane;
   }
   {
     WgradJob jobs[kMaxWgradJobs];
@@ -302,15 +373,15 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
   if (overlap2) {
     if ((rc = side_lane(&lane2, 1)) || (rc = side_fork(lane2, s))) return rc;
     s2 = lane2->stream;
+    scope2.lane = lane2;
   }
   // gradient of the first edge Linear w.r.t. the two per-node projections
   if ((rc = rowsum_source_and_target(plan, wk.gE[0], B, D, wk.dPs, wk.dPd, s))) return rc;   // one launch for both
   // fiber columns of W0_edge and its bias
   {
     SmallWgradArgs a{};
-    a.G = wk.gE[0]; a.S = nullptr; a.S_cols = int(p + 1);
-    a.src = plan->src; a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
-    a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p;
+    a.G = wk.gE[0]; a.S = sv.e_fiber; a.S_cols = int(p + 1); a.S_ld = fiber_ld(p);   // the fiber rows the forward kept
+    a.p = (int)p;
     a.out = ge[0]; a.os = 1; a.of = ldE0; a.colsum = ge[1];
     a.R = B * E; a.D = (int)D;
     if ((rc = launch_small_wgrad(a, wk.sw, s2))) return rc;
@@ -335,8 +406,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
     a.y = grad_x; a.accumulate = 1;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_PLAIN, a, s))) return rc;
   }
-  if (overlap && (rc = side_join(lane, s))) return rc;
-  if (overlap2 && (rc = side_join(lane2, s))) return rc;
+  if ((rc = scope1.finish()) || (rc = scope2.finish())) return rc;
   return BSMS_OK;
 }
 

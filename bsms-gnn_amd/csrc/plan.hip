@@ -33,18 +33,35 @@ int side_lane(SideLane** out, int which) {
     BSMS_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.fork_ev, hipEventDisableTiming));
     BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.join_ev, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.done_ev[k], hipEventDisableTiming));
   }
   *out = &l;
   return BSMS_OK;
 }
+// record + wait are one critical section: the lanes (and their events) are shared by every caller stream / thread of
+// the device, and a wait must see ITS record, not one a concurrent caller slipped in between
 int side_fork(SideLane* lane, hipStream_t main) {
+  std::lock_guard<std::mutex> lock(g_lane_mu);
   BSMS_HIP_CHECK(hipEventRecord(lane->fork_ev, main));
   BSMS_HIP_CHECK(hipStreamWaitEvent(lane->stream, lane->fork_ev, 0));
   return BSMS_OK;
 }
 int side_join(SideLane* lane, hipStream_t main) {
+  std::lock_guard<std::mutex> lock(g_lane_mu);
   BSMS_HIP_CHECK(hipEventRecord(lane->join_ev, lane->stream));
   BSMS_HIP_CHECK(hipStreamWaitEvent(main, lane->join_ev, 0));
+  return BSMS_OK;
+}
+int side_mark(SideLane* lane, int slot) {
+  std::lock_guard<std::mutex> lock(g_lane_mu);
+  BSMS_HIP_CHECK(hipEventRecord(lane->done_ev[slot & 1], lane->stream));
+  lane->marked[slot & 1] = true;
+  return BSMS_OK;
+}
+int side_wait_mark(SideLane* lane, int slot, hipStream_t main) {
+  std::lock_guard<std::mutex> lock(g_lane_mu);
+  if (!lane->marked[slot & 1]) return BSMS_OK;
+  BSMS_HIP_CHECK(hipStreamWaitEvent(main, lane->done_ev[slot & 1], 0));
   return BSMS_OK;
 }
 }  // namespace bsms

@@ -27,6 +27,7 @@ struct RowSumArgs {
   const int32_t* widx;    // optional [E]: slot -> weight index (identity if null)
   const float* x;
   float* out;
+  const float* addend;    // optional [B, n_out, D] (layout of `out`): out = row sum + addend (a fused residual / skip add)
   int64_t x_bstride, out_bstride;  // floats per batch item
   int32_t n_out, B, D;
 };
@@ -97,6 +98,10 @@ __device__ __forceinline__ void rowsum_body(const RowSumArgs& a) {
     for (; q + 8 <= q1; q += 8) acc = rowsum_batch<8, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
     for (; q + 2 <= q1; q += 2) acc = rowsum_batch<2, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
     for (; q < q1; ++q) acc = rowsum_batch<1, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
+    if (a.addend) {   // (row sum) + addend: one more rounded add, exactly what a separate elementwise add would do
+      const float4 ad = *reinterpret_cast<const float4*>(a.addend + b * a.out_bstride + int64_t(r) * a.D + c4 * 4);
+      acc.x += ad.x; acc.y += ad.y; acc.z += ad.z; acc.w += ad.w;
+    }
     *reinterpret_cast<float4*>(ob + c4 * 4) = acc;
   }
 }
@@ -123,9 +128,38 @@ __global__ __launch_bounds__(256) void k_rowsum_pair(RowSumArgs a0, RowSumArgs a
   else rowsum_body<LPR, false, false, DEEP, false, false>(a);
 }
 
-// any D (positions: D = 2 or 3): one thread per output element
-template <bool WEIGHTED, bool MAPPED>
-__global__ __launch_bounds__(256) void k_rowsum_scalar(RowSumArgs a) {
+// any D (positions: D = 2 or 3; 1-D sums): one thread per output element, slots in branch-free batches like rowsum_batch
+// (a one-slot-at-a-time loop costs two dependent round trips per edge: the coarse position restricts -- up to 166
+// edges per row -- took 60-160 us each)
+template <int U, bool WEIGHTED, bool MAPPED, bool HAS_XIDX, bool HAS_WIDX>
+__device__ __forceinline__ float scalar_batch(const RowSumArgs& a, const float* xcol, int q, float acc) {
+  int xr[U];
+  float w[U], v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) xr[u] = HAS_XIDX ? a.xidx[q + u] : q + u;
+  if (MAPPED) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) xr[u] = a.xmap[xr[u]];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int safe = (MAPPED && xr[u] < 0) ? 0 : xr[u];
+    v[u] = xcol[int64_t(safe) * a.D];
+    w[u] = WEIGHTED ? a.w[HAS_WIDX ? a.widx[q + u] : q + u] : 1.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float nxt;
+    if (WEIGHTED) { const float prod = v[u] * w[u]; nxt = acc + prod; }   // contraction is off in this file
+    else nxt = acc + v[u];
+    if (!MAPPED || xr[u] >= 0) acc = nxt;
+  }
+  return acc;
+}
+
+template <bool WEIGHTED, bool MAPPED, bool HAS_XIDX, bool HAS_WIDX>
+__device__ __forceinline__ void scalar_body(const RowSumArgs& a) {
   const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
   const int64_t total = int64_t(a.B) * a.n_out * a.D;
   if (t >= total) return;
@@ -133,19 +167,28 @@ __global__ __launch_bounds__(256) void k_rowsum_scalar(RowSumArgs a) {
   const int64_t br = t / a.D;
   const int b = int(br / a.n_out), r = int(br % a.n_out);
   const int v = a.rows ? a.rows[r] : r;
-  const float* xb = a.x + b * a.x_bstride;
+  const float* xcol = a.x + b * a.x_bstride + c;
   float acc = 0.f;
-  for (int q = a.rowptr[v]; q < a.rowptr[v + 1]; ++q) {
-    int xr = a.xidx ? a.xidx[q] : q;
-    if (MAPPED) {
-      xr = a.xmap[xr];
-      if (xr < 0) continue;
-    }
-    float val = xb[int64_t(xr) * a.D + c];
-    if (WEIGHTED) { const float prod = val * a.w[a.widx ? a.widx[q] : q]; acc = acc + prod; }
-    else acc += val;
+  int q = a.rowptr[v];
+  const int q1 = a.rowptr[v + 1];
+  for (; q + 16 <= q1; q += 16) acc = scalar_batch<16, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
+  for (; q + 4 <= q1; q += 4) acc = scalar_batch<4, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
+  for (; q < q1; ++q) acc = scalar_batch<1, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
+  const int64_t o = b * a.out_bstride + int64_t(r) * a.D + c;
+  if (a.addend) acc += a.addend[o];
+  a.out[o] = acc;
+}
+
+template <bool WEIGHTED, bool MAPPED>
+__global__ __launch_bounds__(256) void k_rowsum_scalar(RowSumArgs a) {
+  const bool hx = a.xidx != nullptr, hw = WEIGHTED && a.widx != nullptr;
+  if (hx) {
+    if (hw) scalar_body<WEIGHTED, MAPPED, true, WEIGHTED>(a);
+    else scalar_body<WEIGHTED, MAPPED, true, false>(a);
+  } else {
+    if (hw) scalar_body<WEIGHTED, MAPPED, false, WEIGHTED>(a);
+    else scalar_body<WEIGHTED, MAPPED, false, false>(a);
   }
-  a.out[b * a.out_bstride + int64_t(r) * a.D + c] = acc;
 }
 
 // below this many lanes the chip is under-filled (256 CUs x 2048 threads) and latency, not bandwidth, is the limit
@@ -321,6 +364,13 @@ extern "C" int bsms_cal_ew(const bsms_plan_t* p, const float* w, float* ec, floa
 
 extern "C" int bsms_edge_conv(const bsms_plan_t* p, const float* x, int64_t B, int64_t D, const float* ew,
                               int aggregating, int pooled, float* out, bsms_stream_t stream) {
+  return bsms::edge_conv_add(p, x, B, D, ew, aggregating, pooled, out, nullptr, as_stream(stream));
+}
+
+// bsms_edge_conv with an optional fused `+ addend` (same layout as `out`): the U-Net's backward adds the gradient that
+// arrived at a skip connection to the adjoint of the restriction (csrc/bsgmp.hip) without a separate elementwise pass.
+int bsms::edge_conv_add(const bsms_plan* p, const float* x, int64_t B, int64_t D, const float* ew, int aggregating,
+                        int pooled, float* out, const float* addend, hipStream_t stream) {
   BSMS_REQUIRE(p && x && ew && out, BSMS_E_INVALID_ARG, "edge_conv: null argument");
   BSMS_REQUIRE(B >= 0 && D >= 1, BSMS_E_SHAPE, "edge_conv: bad B=%lld D=%lld", (long long)B, (long long)D);
   BSMS_REQUIRE(!pooled || p->ids, BSMS_E_INVALID_ARG, "edge_conv: pooled=1 but the plan has no pool (bsms_plan_set_pool)");
@@ -339,7 +389,8 @@ extern "C" int bsms_edge_conv(const bsms_plan_t* p, const float* x, int64_t B, i
     a.x_bstride = (pooled ? p->Nk : p->N) * D;
   }
   a.out_bstride = int64_t(a.n_out) * D;
-  return launch_rowsum(a, as_stream(stream));
+  a.addend = addend;
+  return launch_rowsum(a, stream);
 }
 
 extern "C" int bsms_scatter_rows(const float* h, int64_t B, int64_t Nk, int64_t D, const int64_t* idx, int64_t N,

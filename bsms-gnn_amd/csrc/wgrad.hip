@@ -307,12 +307,20 @@ constexpr int kMaxTiles = 1024;
 // of rows with 16-byte loads (a row of D floats = one burst of D/4 lanes), 256/(D/4) rows in flight per pass;
 // the narrow row is broadcast.  Per-workgroup partials are combined in fixed order by k_small_reduce.
 constexpr int SW_MAXS = 8;
-constexpr int SW_WGS = 1024;
+constexpr int SW_WGS = 512;   // workgroups (= partial blocks the reduce sums); each keeps SW_UNROLL rows per lane in flight
+constexpr int SW_UNROLL = 4;
 
 __device__ __forceinline__ void small_row(const SmallWgradArgs& a, int64_t r, float (&sv)[SW_MAXS]) {
   if (a.S) {
+    const int ld = a.S_ld ? a.S_ld : a.S_cols;
+    if ((ld & 3) == 0) {   // padded rows (the saved fiber): one or two 16-byte loads
+      const float4 lo = *reinterpret_cast<const float4*>(a.S + r * ld);
+      const float4 hi = ld > 4 ? *reinterpret_cast<const float4*>(a.S + r * ld + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sv[0] = lo.x; sv[1] = lo.y; sv[2] = lo.z; sv[3] = lo.w; sv[4] = hi.x; sv[5] = hi.y; sv[6] = hi.z; sv[7] = hi.w;
+    } else {
 #pragma unroll
-    for (int s = 0; s < SW_MAXS; ++s) sv[s] = s < a.S_cols ? a.S[r * a.S_cols + s] : 0.f;
+      for (int s = 0; s < SW_MAXS; ++s) sv[s] = s < a.S_cols ? a.S[r * ld + s] : 0.f;
+    }
   } else {  // fiber [pos_i - pos_j, |pos_i - pos_j|]  (ops/basic.py:83-85)
     const int b = int(r / a.E), q = int(r - int64_t(b) * a.E);
     const int i = a.src[q], jn = a.dst[q];
@@ -349,19 +357,34 @@ __global__ __launch_bounds__(256) void k_small_wgrad(SmallWgradArgs a, float* pa
 #pragma unroll
   for (int s = 0; s < SW_MAXS; ++s) cs[s] = 0.f;
   const int64_t r0 = int64_t(blockIdx.x) * rows_per_wg, r1 = min(a.R, r0 + rows_per_wg);
-  if (active) {
-    for (int64_t r = r0 + rl; r < r1; r += nrl) {
-      const float4 g = *reinterpret_cast<const float4*>(a.G + r * D + c4 * 4);
-      float sv[SW_MAXS];
-      small_row(a, r, sv);
+  if (active && r0 < r1) {
+    // SW_UNROLL rows of this lane in flight: all loads first (unconditional: rows past the slab re-read its last row and
+    // are dropped by a select), then the products in row order -- the sums see the same sequence as a one-row loop
+    for (int64_t r = r0 + rl; r < r1; r += int64_t(SW_UNROLL) * nrl) {
+      float4 g[SW_UNROLL];
+      float sv[SW_UNROLL][SW_MAXS];
+      bool ok[SW_UNROLL];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        acc[s].x = fmaf(g.x, sv[s], acc[s].x); acc[s].y = fmaf(g.y, sv[s], acc[s].y);
-        acc[s].z = fmaf(g.z, sv[s], acc[s].z); acc[s].w = fmaf(g.w, sv[s], acc[s].w);
+      for (int u = 0; u < SW_UNROLL; ++u) {
+        const int64_t rr = r + int64_t(u) * nrl;
+        ok[u] = rr < r1;
+        const int64_t rc = ok[u] ? rr : r1 - 1;
+        g[u] = *reinterpret_cast<const float4*>(a.G + rc * D + c4 * 4);
+        small_row(a, rc, sv[u]);
       }
-      acc[NS].x += g.x; acc[NS].y += g.y; acc[NS].z += g.z; acc[NS].w += g.w;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) cs[s] += sv[s];
+      for (int u = 0; u < SW_UNROLL; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          acc[s].x = fmaf(g[u].x, sv[u][s], acc[s].x); acc[s].y = fmaf(g[u].y, sv[u][s], acc[s].y);
+          acc[s].z = fmaf(g[u].z, sv[u][s], acc[s].z); acc[s].w = fmaf(g[u].w, sv[u][s], acc[s].w);
+        }
+        acc[NS].x += g[u].x; acc[NS].y += g[u].y; acc[NS].z += g[u].z; acc[NS].w += g[u].w;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) cs[s] += sv[u][s];
+      }
     }
   }
   float* out = part + int64_t(blockIdx.x) * (SW_MAXS + 2) * D;
@@ -406,8 +429,18 @@ __global__ __launch_bounds__(256) void k_small_reduce(SmallWgradArgs a, const fl
   // rows 0..S-1: narrow products; row SW_MAXS: colsum(G); row SW_MAXS+1, entries < S: colsum(S)
   const bool valid = o < (SW_MAXS + 2) * D && (s < S || s == SW_MAXS || (s == SW_MAXS + 1 && f < S && a.colsum_S));
   float v = 0.f;
-  if (valid)
-    for (int w = pl; w < nwg; w += 32) v += part[(int64_t(w) * (SW_MAXS + 2) + s) * D + f];
+  if (valid) {
+    const float* col = part + int64_t(s) * D + f;
+    const int64_t pitch = int64_t(SW_MAXS + 2) * D;
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent loads in flight per lane, combined in fixed order
+    int w = pl;
+    for (; w + 96 < nwg; w += 128) {
+      v4[0] += col[int64_t(w) * pitch]; v4[1] += col[int64_t(w + 32) * pitch];
+      v4[2] += col[int64_t(w + 64) * pitch]; v4[3] += col[int64_t(w + 96) * pitch];
+    }
+    for (; w < nwg; w += 32) v4[0] += col[int64_t(w) * pitch];
+    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+  }
   red[threadIdx.x] = v;
   __syncthreads();
   if (pl == 0 && valid) {
@@ -420,8 +453,12 @@ __global__ __launch_bounds__(256) void k_small_reduce(SmallWgradArgs a, const fl
 
 }  // namespace
 
+#ifdef BSMS_EXPERIMENTS
 static unsigned long long* g_wgrad_timing = nullptr;
 extern "C" void bsms_debug_set_wgrad_timing(unsigned long long* dev_buf) { g_wgrad_timing = dev_buf; }  // experiments only
+#else
+constexpr unsigned long long* g_wgrad_timing = nullptr;
+#endif
 
 namespace bsms {
 

@@ -23,8 +23,9 @@ class GradBuckets:
     arrive from plain autograd are copied in by the hook.  A bucket is all-reduced as soon as all of its
     parameters have their gradient."""
 
-    def __init__(self, params, bucket_bytes=2 << 20, group=None):
+    def __init__(self, params, bucket_bytes=2 << 20, group=None, overlap=True):
         self.group = group
+        self.overlap = overlap   # False: every bucket is reduced in finish() (after backward)
         self.params = [p for p in params if p.requires_grad]
         order = list(reversed(self.params))  # roughly the order backward produces them
         total = sum(p.numel() for p in order)
@@ -46,6 +47,7 @@ class GradBuckets:
         if cur:
             self._close(start, off, cur)
         self._pending, self._handles = [len(b["params"]) for b in self.buckets], []
+        self._seen, self._launched = set(), set()
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -62,8 +64,20 @@ class GradBuckets:
             view.copy_(p.grad)
             p.grad = view
         b = self._bucket_of[p]
+        if p in self._seen:
+            # second gradient of the same parameter in one backward (a module used twice, accumulation without zero()):
+            # the early reduction of its bucket would miss it -- such a bucket is reduced in finish() instead
+            if b in self._launched:
+                raise RuntimeError("GradBuckets: a parameter received a second gradient after its bucket was all-reduced; "
+                                   "call zero() between backward passes or disable bucket overlap")
+            self._pending[b] = -1
+            return
+        self._seen.add(p)
+        if self._pending[b] < 0:
+            return
         self._pending[b] -= 1
-        if self._pending[b] == 0 and self._world() > 1:
+        if self._pending[b] == 0 and self._world() > 1 and self.overlap:
+            self._launched.add(b)
             self._handles.append(dist.all_reduce(self.buckets[b]["view"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _world(self):
@@ -75,12 +89,15 @@ class GradBuckets:
             p.grad = None
             p._bsms_slot_used = False
         self._pending = [len(b["params"]) for b in self.buckets]
+        self._seen.clear()
+        self._launched.clear()
 
     def finish(self):
         """Wait for the in-flight bucket reductions (call after backward)."""
         if self._world() > 1:
-            for b, left in enumerate(self._pending):  # buckets holding parameters that got no gradient this step
-                if 0 < left:
+            for b, left in enumerate(self._pending):  # buckets not reduced during backward (missing / repeated gradients)
+                if b not in self._launched:
+                    self._launched.add(b)
                     self._handles.append(dist.all_reduce(self.buckets[b]["view"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for h in self._handles:
             h.wait()
@@ -116,14 +133,12 @@ class DataParallel:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=group)
-            # With more than one rank the U-Net runs as the per-block module tree rather than the single
-            # bsms_bsgmp_fwd/_bwd call: its weight gradients then reach autograd block by block, so the bucket
-            # all-reduces start during backward instead of after the whole U-Net (same kernels, bit-identical results;
-            # the host has the time: ~5.4 ms of enqueue against a 7.6 ms GPU step).  BSMS_PY_BSGMP=0/1 overrides.
-            import os
-            from . import ops
-            if "BSMS_PY_BSGMP" not in os.environ:
-                ops._PY_BSGMP = True
+        # The U-Net stays ONE bsms_bsgmp_fwd / _bwd call per step under data parallelism too: eight ranks share one
+        # host, and the per-block module tree costs every rank ~3x the enqueue time to buy an overlap worth < 3 % (the
+        # whole gradient is 7.7 MB: ~0.1-0.2 ms of ring all-reduce over xGMI against a 6-7 ms step).  Buckets complete
+        # as autograd hands the gradients over (decoder first, then the whole U-Net, then the encoder) and are
+        # all-reduced asynchronously from there.  A model built with BSGMP.per_block = True (BSMS_PY_BSGMP=1) still
+        # gets block-by-block overlap.
         self.grads = GradBuckets(list(model.parameters()), bucket_bytes, group)
 
     def __call__(self, *a, **k):

@@ -15,7 +15,10 @@ from . import _abi
 class LevelPlan:
     """One mesh level (optionally with the kept-node ids of the level for restrict/prolong)."""
 
+    constructed = 0   # number of plans built so far (tests assert that a consistent mesh builds its plans ONCE)
+
     def __init__(self, g, num_nodes, ids=None, device=None):
+        LevelPlan.constructed += 1
         g_cpu = g.detach().to("cpu", torch.int64).contiguous()
         if g_cpu.dim() != 2 or g_cpu.shape[0] != 2:
             raise ValueError(f"edge list must be [2, E], got {tuple(g_cpu.shape)}")
@@ -72,7 +75,7 @@ class _PlanCache:
     """LRU keyed by the identity of the index tensors' storage (+ version counter).  Each entry keeps
     the storages alive, so a cached address can never be recycled for a different graph."""
 
-    def __init__(self, capacity=256):
+    def __init__(self, capacity=64):
         self.capacity = capacity
         self._d = OrderedDict()
 
@@ -102,6 +105,48 @@ def plan_for(g, num_nodes, ids=None):
 
 def clear_plan_cache():
     _CACHE.clear()
+    _INTERNED.clear()
+
+
+# ------------------------------------------------------------------------------------ interned index tensors
+# A training loop that follows the reference (trainer/trainer.py:143 `move_to_device` on every batch) hands the model
+# FRESH device copies of the same edge lists every step; a cache keyed on tensor identity then misses every step and
+# every miss costs a device->host copy, a host CSR build and ~10 synchronous allocations.  Index tensors are therefore
+# interned by CONTENT while they are still on the host: equal content -> the same device tensor object -> the identity
+# keyed plan cache hits, and the edge lists are not re-uploaded either.
+_INTERNED = OrderedDict()
+_INTERN_CAPACITY = 64
+
+
+def _content_key(t):
+    import xxhash
+    a = np.ascontiguousarray(t.numpy())
+    return (tuple(t.shape), str(t.dtype), xxhash.xxh64_intdigest(a.view(np.uint8).reshape(-1)))
+
+
+def intern_index(t, device, shared_batch_axis=False):
+    """Device copy of the CPU int64 index tensor `t`, shared between calls with equal content.
+    shared_batch_axis: `t` is [B, ...] and the consumer reads t[0] only (consistent-mesh collate, models/model.py:190-192);
+    when all B slices are equal only ONE slice is uploaded and the result is an expanded (stride-0) view, so the cache
+    does not pin B copies of the edge list in HBM."""
+    if t.is_cuda or t.dtype != torch.int64:
+        return t.to(device)
+    first = None
+    if shared_batch_axis and t.dim() >= 2 and t.shape[0] >= 1 and bool((t == t[:1]).all()):
+        first = t[0]
+    key = (_content_key(first if first is not None else t), t.shape[0] if first is not None else -1, str(device))
+    hit = _INTERNED.get(key)
+    if hit is not None:
+        _INTERNED.move_to_end(key)
+        return hit
+    if first is not None:
+        dev = first.contiguous().to(device).unsqueeze(0).expand(t.shape[0], *first.shape)
+    else:
+        dev = t.to(device)
+    _INTERNED[key] = dev
+    if len(_INTERNED) > _INTERN_CAPACITY:
+        _INTERNED.popitem(last=False)
+    return dev
 
 
 class LevelData:
@@ -112,9 +157,10 @@ class LevelData:
     def __init__(self, edge_index, num_nodes, face=None, x=None, y=None, mask=None):
         self.edge_index, self.num_nodes, self.face, self.x, self.y, self.mask = edge_index, num_nodes, face, x, y, mask
 
-    def to(self, device):
+    def to(self, device, intern=False):
         mv = lambda t: None if t is None else t.to(device)
-        return LevelData(mv(self.edge_index), self.num_nodes, mv(self.face), mv(self.x), mv(self.y), mv(self.mask))
+        mi = (lambda t: None if t is None else intern_index(t, device)) if intern else mv
+        return LevelData(mi(self.edge_index), self.num_nodes, mi(self.face), mv(self.x), mv(self.y), mv(self.mask))
 
 
 def collate_variable_meshes(samples):

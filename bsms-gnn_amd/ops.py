@@ -109,6 +109,8 @@ def scatter_sum(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Opti
     d = dim if dim >= 0 else nd + dim
     if index.dim() != 1 or not ((nd == 1 and d == 0) or (nd in (2, 3) and d == nd - 2)):
         raise NotImplementedError("scatter_sum: only a 1-D index along the edge axis ([E], [E,D], [B,E,D]) is implemented")
+    if index.numel() != src.shape[d]:
+        raise RuntimeError(f"scatter_sum: index has {index.numel()} entries, src has {src.shape[d]} along dim {dim}")
     if dim_size is None:
         dim_size = 0 if index.numel() == 0 else int(index.max()) + 1
     plan = _index_plan(index, dim_size)
@@ -235,6 +237,19 @@ class MLP(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------ GMP
+def _check_gmp_shapes(who, x, pos, plan, latent_dim, pos_dim):
+    """The C ABI takes raw pointers and sizes: what the reference would report as a PyTorch shape error must be caught
+    here, before it becomes an out-of-bounds device access."""
+    if x.shape[-1] != latent_dim:
+        raise RuntimeError(f"{who}: feature width {x.shape[-1]} does not match latent_dim {latent_dim}")
+    if pos.shape[-1] != pos_dim:
+        raise RuntimeError(f"{who}: position width {pos.shape[-1]} does not match pos_dim {pos_dim}")
+    if x.shape[-2] != plan.N or pos.shape[-2] != plan.N:
+        raise RuntimeError(f"{who}: x has {x.shape[-2]} and pos {pos.shape[-2]} nodes, the graph has {plan.N}")
+    if pos.dim() == 3 and x.dim() == 3 and pos.shape[0] != x.shape[0]:
+        raise RuntimeError(f"{who}: batch of pos ({pos.shape[0]}) differs from batch of x ({x.shape[0]})")
+
+
 def _gmp_infer(x, pos, plan, hidden, params):
     """Forward only (`saved` = NULL at the ABI): used by rollout / evaluation under torch.no_grad()."""
     B, N, D = x.shape
@@ -308,6 +323,7 @@ class GMP(nn.Module):
             x = x.unsqueeze(0)
         if plan is None:
             plan = plan_for(g, x.shape[-2])
+        _check_gmp_shapes("GMP", x, pos, plan, self.latent_dim, self.pos_dim)
         params = [*self.mlp_node.flat_params(), *self.mlp_edge.flat_params()]
         if _needs_grad(x, *params):
             y = _GMPFunction.apply(x, pos, plan, self.hidden_layer, *params)
@@ -360,6 +376,10 @@ class WeightedEdgeConv(nn.Module):
         ew = _dev_f32(ew, "WeightedEdgeConv")
         if plan is None:
             plan = plan_for(g, x.shape[-2])
+        if ew.numel() != plan.E:
+            raise RuntimeError(f"WeightedEdgeConv: {ew.numel()} edge weights for {plan.E} edges")
+        if x.shape[-2] != plan.N:
+            raise RuntimeError(f"WeightedEdgeConv: x has {x.shape[-2]} nodes, the graph has {plan.N}")
         return _edge_conv(x, ew, plan, bool(aggragating), False)
 
     @torch.no_grad()
@@ -401,6 +421,22 @@ class _ScatterRows(torch.autograd.Function):
         return gh, None, None
 
 
+_RANGE_OK = {}
+
+
+def _check_index_range(idx, n):
+    """0 <= idx < n, validated ONCE per index tensor (storage identity + version): the check needs a device sync."""
+    from .graph import _key
+    key = (_key(idx), n)
+    if key in _RANGE_OK:
+        return
+    if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n):
+        raise IndexError(f"Unpool: index out of range for {n} rows")
+    if len(_RANGE_OK) > 1024:
+        _RANGE_OK.clear()
+    _RANGE_OK[key] = idx.untyped_storage()   # keeps the address from being recycled for another tensor
+
+
 class Unpool(nn.Module):
     """ops/basic.py:170-201."""
 
@@ -410,6 +446,9 @@ class Unpool(nn.Module):
     def forward(self, h, pre_node_num, idx):
         h = _dev_f32(h, "Unpool")
         idx = idx.to(torch.int64).contiguous()
+        if idx.numel() != h.shape[-2]:
+            raise RuntimeError(f"Unpool: {idx.numel()} indices for {h.shape[-2]} rows")
+        _check_index_range(idx, int(pre_node_num))
         if h.dim() == 2:
             return _ScatterRows.apply(h.unsqueeze(0), idx, int(pre_node_num)).squeeze(0)
         if h.dim() == 3:
@@ -492,6 +531,8 @@ class BSGMP(nn.Module):
         self.up_gmps = nn.ModuleList()
         self.unpools = nn.ModuleList()
         self.unet_depth = unet_depth
+        self.latent_dim, self.pos_dim = latent_dim, pos_dim
+        self.per_block = _PY_BSGMP   # True: one autograd node per block / transition (module tree) instead of one call
         self.edge_conv = WeightedEdgeConv()
         for _ in range(unet_depth):
             self.down_gmps.append(GMP(latent_dim, hidden_layer, pos_dim))
@@ -528,7 +569,9 @@ class BSGMP(nn.Module):
             plans.append(plan_for(m_gs[i], n_l, m_ids[i]))
             n_l = plans[-1].Nk
         ews = self._edge_weights(plans, m_ids, pos.device)
-        if not _PY_BSGMP:   # the whole U-Net in one library call (csrc/bsgmp.hip)
+        if plans:
+            _check_gmp_shapes("BSGMP", h, pos, plans[0], self.latent_dim, self.pos_dim)
+        if not self.per_block:   # the whole U-Net in one library call (csrc/bsgmp.hip)
             squeeze = h.dim() == 2
             if squeeze:
                 if pos.dim() == 3:

@@ -84,8 +84,16 @@ class Trainer:
         self._synced = False
 
     def move_to_device(self, data):
+        """trainer/trainer.py:143 semantics (nested lists -> device), except that INDEX tensors (edge lists, kept ids)
+        are interned by content (graph.intern_index): a batch of the same mesh maps to the same device tensors every
+        step, so the per-mesh plans (CSR layouts, edge weights) are built once, not once per step."""
+        from .graph import LevelData, intern_index
         if isinstance(data, (list, tuple)):
             return [self.move_to_device(d) for d in data]
+        if isinstance(data, LevelData):
+            return data.to(self.device, intern=True)
+        if data.dtype == torch.int64 and not data.is_cuda:
+            return intern_index(data, self.device, shared_batch_axis=bool(self.model_cfg.consistent_mesh))
         return data.to(self.device)
 
     def _warming_up(self):
@@ -140,3 +148,6 @@ class Trainer:
             self.optimizer.load_state_dict(st["opt"])
             self.lr_scheduler.last_epoch = st["epoch"]
             self.train_step = st["train_step"]
+        # restored normaliser statistics are already the merged ones: never re-run the cross-rank merge on them
+        # (it would multiply _acc_weight / _num_accumulations by the world size)
+        self._synced = True

@@ -16,10 +16,13 @@ Tolerances (BASELINE.json north_star: 1e-5 relative fp32)
     and which side of the kink they land on differs between ANY two fp32 summation orders -- so "GPU within 1e-5 of
     CPU fp32" is not a property even two runs of the reference on different BLAS builds have.  What is required:
         e_gpu(p) = max|g_gpu - g_64| / max|g_64| ,  e_cpu(p) likewise for the fp32 oracle
-        (a) worst tensor:   max_p e_gpu <= max(1e-5, 2 * max_p e_cpu)
-        (b) typical tensor: median_p e_gpu <= max(1e-5, 1.5 * median_p e_cpu)
-        (c) at most 10 % of the tensors have e_gpu > max(1e-5, 2 * e_cpu(p))
-    i.e. the engine is as close to the exact gradient as the reference's fp32 path is.
+        (a) worst tensor:    max_p e_gpu            <= max(1e-5, 2   * max_p e_cpu)
+        (b) typical tensor:  median_p e_gpu         <= max(1e-5, 1.5 * median_p e_cpu)
+        (c) tail:            90th percentile e_gpu  <= max(1e-5, 1.5 * 90th percentile e_cpu)
+    i.e. the engine's distance to the exact gradient has the same distribution over the parameter tensors as the
+    reference's own fp32 path (a per-tensor ratio is not meaningful: which tensors a near-zero ReLU input lands in is
+    random for both implementations).  First MI355X run, airfoil: gpu worst 9.4e-5 / median 1.0e-5, cpu32 worst
+    9.3e-5 / median 8.1e-6, gpu-vs-cpu32 directly worst 4.3e-5 / median 8.3e-6; loss equal to 8e-8, pred to 2.5e-7.
 """
 import os
 import time
@@ -112,15 +115,15 @@ def check(r, tag):
     e_cpu = np.array([_rel(r["g32"][k], r["g64"][k]) for k in keys])
     direct = np.array([_rel(r["gg"][k], r["g32"][k]) for k in keys])
     worst = int(np.argmax(e_gpu))
-    over = (e_gpu > np.maximum(1e-5, 2 * e_cpu))
+    p90g, p90c = np.percentile(e_gpu, 90), np.percentile(e_cpu, 90)
     print(f"\n[{tag}] levels {r['levels']}\n  oracle fp32 {r['t32']:.1f} s, fp64 {r['t64']:.1f} s; loss gpu {r['loss']:.7f} "
           f"cpu32 {r['loss32']:.7f} f64 {r['loss64']:.7f}; pred max-norm {float(diff.max()) / scale:.2e}\n"
           f"  grads vs fp64 over {len(keys)} tensors: gpu worst {e_gpu.max():.2e} ({keys[worst]}) median {np.median(e_gpu):.2e} | "
           f"cpu32 worst {e_cpu.max():.2e} median {np.median(e_cpu):.2e} | gpu-vs-cpu32 worst {direct.max():.2e} "
-          f"median {np.median(direct):.2e} | tensors over: {int(over.sum())}")
+          f"median {np.median(direct):.2e} | p90 gpu {p90g:.2e} cpu32 {p90c:.2e}")
     assert e_gpu.max() <= max(1e-5, 2 * e_cpu.max()), (tag, "worst tensor", keys[worst], e_gpu.max(), e_cpu.max())
     assert np.median(e_gpu) <= max(1e-5, 1.5 * np.median(e_cpu)), (tag, "median", np.median(e_gpu), np.median(e_cpu))
-    assert over.sum() <= 0.10 * len(keys), (tag, "tensors over", [keys[i] for i in np.flatnonzero(over)][:8])
+    assert p90g <= max(1e-5, 1.5 * p90c), (tag, "90th percentile", p90g, p90c)
 
 
 @pytest.fixture(scope="module")

@@ -3,7 +3,8 @@ the golden vectors generated from the reference.
 
 Tolerances: integer / index results bit-exact; segment sums, edge weights and transitions are summed in
 the reference's edge order and must be BIT-IDENTICAL to the CPU result; dense fp32 results within
-1e-5 of the tensor scale (max|a-b| / max|b|, BASELINE.json north_star), gradients 2e-5."""
+1e-5 of the tensor scale (max|a-b| / max|b|, BASELINE.json north_star), gradients likewise 1e-5 (data kept away from
+ReLU kinks, conftest.KinkMargin; at full size the three-way fp64 criterion of tests/test_hip_fullsize.py applies)."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +13,7 @@ from conftest import load_golden, pick_seed, rel_err
 from oracle import bsms_oracle as ro
 
 pytestmark = pytest.mark.gpu
-FWD_TOL, BWD_TOL = 1e-5, 2e-5
+FWD_TOL, BWD_TOL = 1e-5, 1e-5
 
 
 @pytest.fixture(scope="module")
@@ -325,7 +326,7 @@ def test_bsgmp_single_call_equals_module_tree(eng, graphs):
     net = load_sd(eng.BSGMP(L, 32, 3, 2), z.state_dict())
     res = {}
     for mode in (False, True):
-        ops._PY_BSGMP = mode
+        net.per_block = mode
         try:
             net.zero_grad()
             h = dev(z.t("h")).requires_grad_(True)
@@ -335,7 +336,7 @@ def test_bsgmp_single_call_equals_module_tree(eng, graphs):
                 yi = net(h.detach(), [dev(i) for i in ids[:L]], [dev(e) for e in es[: L + 1]], dev(z.t("pos")))
             res[mode] = (y.detach().clone(), h.grad.clone(), [q.grad.clone() for q in net.parameters()], yi.clone())
         finally:
-            ops._PY_BSGMP = False
+            net.per_block = False
     a, b = res[False], res[True]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
     assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
@@ -362,7 +363,7 @@ def test_bsgmp_single_call_layouts(eng):
         net = net.cuda()
         res = {}
         for mode in (False, True):
-            ops._PY_BSGMP = mode
+            net.per_block = mode
             try:
                 net.zero_grad()
                 h = dev(h0).requires_grad_(True)
@@ -370,7 +371,7 @@ def test_bsgmp_single_call_layouts(eng):
                 y.square().sum().backward()
                 res[mode] = (y.detach().clone(), h.grad.clone(), [q.grad.clone() for q in net.parameters()])
             finally:
-                ops._PY_BSGMP = False
+                net.per_block = False
         a, b = res[False], res[True]
         assert a[0].shape == h0.shape and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))

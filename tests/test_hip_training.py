@@ -88,6 +88,13 @@ def test_trainer_iterations_follow_cpu_reference_loop(eng, graphs, tmp_path):
         if out is not None:
             losses.append(float(out))
     assert len(losses) == 4 and tr.train_step == 5
+    # the CPU batch goes through move_to_device every iteration (trainer/trainer.py:143): the mesh plans must have been
+    # built during the first iteration only (index tensors interned by content, graph.intern_index)
+    from bsms_gnn_amd.graph import LevelPlan
+    built = LevelPlan.constructed
+    fresh = (data[0].clone(), data[1].clone(), data[2].clone(), [g.clone() for g in m_gs], [i.clone() for i in m_ids])
+    tr.get_loss(fresh)                                   # NEW host tensors, same mesh: still no plan construction
+    assert LevelPlan.constructed == built, "a consistent mesh rebuilt its plans"
     for a, b in zip(losses, losses_ref):
         assert abs(a - b) < 2e-4 * abs(b), (losses, losses_ref)
     assert losses[-1] < losses[1]                                                   # it actually learns
@@ -120,10 +127,14 @@ def test_datapipe_to_trainer_end_to_end(eng, consistent):
     torch.manual_seed(0)
     tr = eng.Trainer(eng.BSMS_Simulator(model_cfg), model_cfg, opt_cfg)
     losses = []
+    from bsms_gnn_amd.graph import LevelPlan
+    built = []
     for it, batch in enumerate(loader):
-        data = [d.to("cuda") for d in batch] if not consistent else batch
-        out = tr.iter(data)
+        out = tr.iter(batch)                             # host batches, moved (and interned) by the Trainer itself
+        built.append(LevelPlan.constructed)
         if out is not None:
             losses.append(float(out))
     assert len(losses) >= 2 and all(np.isfinite(losses))
+    if consistent:
+        assert built[-1] == built[1], "plans of a consistent mesh are built once (warm-up builds none, step 1 builds them)"
     assert float(tr.optimizer.grad_norm) > 0
