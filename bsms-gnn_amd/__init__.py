@@ -5,10 +5,11 @@ libbsms_hip.so (include/bsms_hip.h).  Import name: `bsms_gnn_amd` (directory: `b
 from . import _abi  # noqa: F401
 from .graph import LevelData, LevelPlan, clear_plan_cache, collate_variable_meshes, plan_for  # noqa: F401
 from .model import BSMS_Simulator, Normalizer, masked_rmse, masked_se_sums  # noqa: F401
-from .ops import BSGMP, GMP, MLP, Unpool, WeightedEdgeConv, degree, scatter_sum  # noqa: F401
+from .ops import BSGMP, GMP, MLP, InferenceSession, Unpool, WeightedEdgeConv, degree, scatter_sum  # noqa: F401
 from .dp import DataParallel, GradBuckets, global_masked_rmse  # noqa: F401
 from .hierarchy import BistrideMultiLayerGraph, to_flat_edge  # noqa: F401
-from .rollout import rollout_one_traj, rollout_rmse  # noqa: F401
+from .rollout import rollout_batch, rollout_one_traj, rollout_rmse  # noqa: F401
+from .step import FusedStep  # noqa: F401
 from .trainer import FusedAdamW, Trainer, WarmupCosineDecay  # noqa: F401
 
 __version__ = "0.1.0"

@@ -44,8 +44,16 @@ SIGNATURES = {
     "bsms_bsgmp_work_bytes": (c_size_t, [PP, c_int, c_i64, c_i64, c_i64, c_int]),
     "bsms_bsgmp_fwd": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
+    "bsms_bsgmp_fwd_ex": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p, c_void_p,
+                                  c_void_p, c_int, c_void_p]),
     "bsms_bsgmp_bwd": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
                                c_void_p, c_void_p, PP, c_void_p]),
+    "bsms_sim_work_bytes": (c_size_t, [c_i64]),
+    "bsms_sim_prologue": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bsms_sim_epilogue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bsms_sim_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
     "bsms_hierarchy_create": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, PP]),
     "bsms_hierarchy_create_f32": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, PP]),
     "bsms_hierarchy_destroy": (c_int, [c_void_p]),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libbsms_hip.so")
-SOURCES = ["plan.hip", "rowsum.hip", "chain.hip", "wgrad.hip", "gmp.hip", "bsgmp.hip", "optim.hip", "hierarchy.hip"]
+SOURCES = ["plan.hip", "rowsum.hip", "chain.hip", "wgrad.hip", "gmp.hip", "bsgmp.hip", "optim.hip", "hierarchy.hip", "sim.hip"]
 HEADERS = ["common.h", "chain.h", os.path.join("..", "..", "include", "bsms_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("BSMS_EXPERIMENTS") == "1":   # profiling / A-B builds only: BSMS_DEBUG_FLAGS, in-kernel time stamps
@@ -42,7 +42,8 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        extra = ["-ffp-contract=off"] if src == "rowsum.hip" else []  # bit-exact x*ew then add (see rowsum.hip)
+        # no contraction: rowsum.hip rounds x*ew before the add like the reference; sim.hip keeps the fp64 normaliser roundings
+        extra = ["-ffp-contract=off"] if src in ("rowsum.hip", "sim.hip") else []
         cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

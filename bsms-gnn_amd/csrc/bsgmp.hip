@@ -123,6 +123,12 @@ extern "C" size_t bsms_bsgmp_work_bytes(const bsms_plan_t* const* plans, int L, 
 extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
                               int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                               const float* const* params, float* out, void* saved, void* work, bsms_stream_t stream) {
+  return bsms_bsgmp_fwd_ex(plans, ew, L, h, pos, B, D, p, pos_batch_stride, hidden, params, out, saved, work, 0, stream);
+}
+
+extern "C" int bsms_bsgmp_fwd_ex(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                                 int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                                 const float* const* params, float* out, void* saved, void* work, int reuse, bsms_stream_t stream) {
   Shape s;
   int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_fwd");
   if (rc) return rc;
@@ -140,26 +146,32 @@ extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* cons
   const float* pos_l[kMaxLevels + 1];
   int64_t pstride_l[kMaxLevels + 1];
   pos_l[0] = pos; pstride_l[0] = pos_batch_stride;
+  // `reuse` (inference only; the caller passes the SAME work buffer as in its previous call and nothing else wrote to
+  // it): bit 0 = the weights have not changed, the packs in `work` are still valid; bit 1 = pos and the mesh have not
+  // changed, the coarse positions in `work` are still valid.  An autoregressive rollout sets both after its first step.
+  const bool packs_ok = !training && (reuse & 1), pos_ok = !training && (reuse & 2);
   SideLane *lane = nullptr, *lane0 = nullptr;
   auto packs_of = [&](int k) { return training ? nullptr : w.packs[k]; };
   if (L > 0) {
-    if ((rc = side_lane(&lane, 1)) || (rc = side_fork(lane, st))) return rc;
+    if (!pos_ok && ((rc = side_lane(&lane, 1)) || (rc = side_fork(lane, st)))) return rc;
     for (int i = 0; i < L; ++i) {
-      if ((rc = bsms_edge_conv(plans[i], pos_l[i], posB, p, ew[i], 1, 1, v.pos[i + 1], lane->stream))) return rc;
+      if (!pos_ok && (rc = bsms_edge_conv(plans[i], pos_l[i], posB, p, ew[i], 1, 1, v.pos[i + 1], lane->stream))) return rc;
       pos_l[i + 1] = v.pos[i + 1];
       pstride_l[i + 1] = pos_batch_stride ? s.N[i + 1] * p : 0;
     }
-    if ((rc = side_lane(&lane0, 0)) || (rc = side_fork(lane0, st))) return rc;
-    for (int k = 1; k <= 2 * L; ++k) {
-      const int lv = level_of_block(k, L);
-      if ((rc = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream))) return rc;
+    if (!packs_ok) {
+      if ((rc = side_lane(&lane0, 0)) || (rc = side_fork(lane0, st))) return rc;
+      for (int k = 1; k <= 2 * L; ++k) {
+        const int lv = level_of_block(k, L);
+        if ((rc = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream))) return rc;
+      }
     }
   }
   const float* hi = h;
   for (int i = 0; i < L; ++i) {
     if ((rc = gmp_fwd_core(plans[i], hi, pos_l[i], B, D, p, pstride_l[i], hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp,
-                           packs_of(i), i == 0, nullptr, st))) return rc;
-    if (i == 0 && ((rc = side_join(lane, st)) || (rc = side_join(lane0, st)))) return rc;
+                           packs_of(i), i == 0 && !packs_ok, nullptr, st))) return rc;
+    if (i == 0 && ((lane && (rc = side_join(lane, st))) || (lane0 && (rc = side_join(lane0, st))))) return rc;
     // restrict the features to the kept nodes (ops/BSMS.py:74, 79-83)
     if ((rc = bsms_edge_conv(plans[i], w.skip[i], B, D, ew[i], 1, 1, v.hin[i + 1], stream))) return rc;
     hi = v.hin[i + 1];
@@ -168,7 +180,7 @@ extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* cons
   const int64_t pstride = pstride_l[L];
   float* cur = (L == 0) ? out : w.a[0];
   if ((rc = gmp_fwd_core(plans[L], hi, pi, B, D, p, pstride, hidden, block(params, L, hidden), cur, v.gmp[L], w.gmp, packs_of(L),
-                         L == 0, nullptr, st))) return rc;
+                         L == 0 && !packs_ok, nullptr, st))) return rc;
   for (int i = 0; i < L; ++i) {
     const int d = L - 1 - i;
     if ((rc = bsms_edge_conv(plans[d], cur, B, D, ew[d], 0, 1, v.upin[d], stream))) return rc;   // prolong (BSMS.py:98-100)
@@ -209,11 +221,13 @@ extern "C" int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* cons
   SideLane *lane0 = nullptr, *lane1 = nullptr;
   if ((rc = side_lane(&lane0, 0)) || (rc = side_lane(&lane1, 1))) return rc;
   int nblk = 0;
+  bool marked[2] = {false, false};   // slots this call has marked (gmp_bwd_core marks both lanes of its slot)
   auto run_block = [&](int level, const float* x, const float* g_in, int k, float* gx) -> int {
     const int slot = nblk & 1;
     int r;
-    if (nblk >= 2 && ((r = side_wait_mark(lane0, slot, st)) || (r = side_wait_mark(lane1, slot, st)))) return r;
+    if (marked[slot] && ((r = side_wait_mark(lane0, slot, st)) || (r = side_wait_mark(lane1, slot, st)))) return r;
     ++nblk;
+    marked[slot] = true;
     return gmp_bwd_core(plans[level], x, pos_l[level], g_in, B, D, p, pstride_l[level], hidden, block(params, k, hidden), v.gmp[k],
                         slot ? w.gmp_b : w.gmp, gx, block(grads, k, hidden), slot, st);
   };
@@ -245,6 +259,6 @@ extern "C" int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* cons
   }
   // every weight gradient has to be complete when the call returns
   for (int slot = 0; slot < 2; ++slot)
-    if ((rc = side_wait_mark(lane0, slot, st)) || (rc = side_wait_mark(lane1, slot, st))) return rc;
+    if (marked[slot] && ((rc = side_wait_mark(lane0, slot, st)) || (rc = side_wait_mark(lane1, slot, st)))) return rc;
   return BSMS_OK;
 }

@@ -45,14 +45,14 @@ struct SideLane {
   hipStream_t stream = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   hipEvent_t done_ev[2] = {nullptr, nullptr};   // "everything queued on the lane up to here has run", two slots
-  bool marked[2] = {false, false};
 };
 constexpr int kSideLanes = 2;
 int side_lane(SideLane** out, int which = 0);        // for the current device; `which` < kSideLanes
 int side_fork(SideLane* lane, hipStream_t main);     // side waits for main
 int side_join(SideLane* lane, hipStream_t main);     // main waits for side
 // Deferred join: side_mark records "the lane's work so far" into slot 0/1; side_wait_mark makes `main` wait for what
-// that slot recorded last (no-op if never marked).  The U-Net backward lets the weight gradients of block k run
+// that slot recorded last (callers only wait on slots they marked themselves: a stale record from an earlier call
+// would be an event from outside an ongoing graph capture).  The U-Net backward lets the weight gradients of block k run
 // under the gradient chain of block k+1 and only waits for them before block k+2 reuses their scratch (bsgmp.hip).
 int side_mark(SideLane* lane, int slot);
 int side_wait_mark(SideLane* lane, int slot, hipStream_t main);

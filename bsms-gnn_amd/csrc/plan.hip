@@ -55,12 +55,10 @@ int side_join(SideLane* lane, hipStream_t main) {
 int side_mark(SideLane* lane, int slot) {
   std::lock_guard<std::mutex> lock(g_lane_mu);
   BSMS_HIP_CHECK(hipEventRecord(lane->done_ev[slot & 1], lane->stream));
-  lane->marked[slot & 1] = true;
   return BSMS_OK;
 }
 int side_wait_mark(SideLane* lane, int slot, hipStream_t main) {
   std::lock_guard<std::mutex> lock(g_lane_mu);
-  if (!lane->marked[slot & 1]) return BSMS_OK;
   BSMS_HIP_CHECK(hipStreamWaitEvent(main, lane->done_ev[slot & 1], 0));
   return BSMS_OK;
 }

@@ -140,12 +140,21 @@ class DataParallel:
         # all-reduced asynchronously from there.  A model built with BSGMP.per_block = True (BSMS_PY_BSGMP=1) still
         # gets block-by-block overlap.
         self.grads = GradBuckets(list(model.parameters()), bucket_bytes, group)
+        # The step itself: direct C-ABI calls on static buffers (step.FusedStep) when the model is the standard
+        # BSMS_Simulator; otherwise (or with BSMS_FUSED_STEP=0) autograd over the drop-in modules.
+        import os
+        from .step import FusedStep
+        self.fused = None
+        if os.environ.get("BSMS_FUSED_STEP", "1") == "1" and FusedStep.supports(model) and next(model.parameters()).is_cuda:
+            self.fused = FusedStep(model, self.grads, group, use_graph=os.environ.get("BSMS_STEP_GRAPH", "0") == "1")
 
     def __call__(self, *a, **k):
         return self.model(*a, **k)
 
     def step_loss_backward(self, data, consistent_mesh=True):
         """One fwd + exact global loss + bwd + gradient reduction.  Returns the (global) loss."""
+        if self.fused is not None:
+            return self.fused(data, consistent_mesh)
         self.grads.zero()
         pred = self.model(data, consistent_mesh, False)
         loss = global_masked_rmse(pred, data[1] if consistent_mesh else data[0].y.unsqueeze(0),

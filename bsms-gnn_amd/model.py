@@ -5,7 +5,8 @@ elementwise PyTorch-ROCm ops (host plumbing)."""
 import torch
 from torch import nn
 
-from .ops import BSGMP, MLP
+from . import _abi
+from .ops import BSGMP, MLP, _stream
 
 
 class Normalizer(nn.Module):
@@ -113,6 +114,36 @@ class BSMS_Simulator(nn.Module):
         pred_delta = self._targetNormalizer.inverse(norm_pred) * node_mask
         return node_in[..., : pred_delta.shape[-1]] + pred_delta
 
+    def _infer(self, m_ids, m_gs, node_in, node_mask, next_in=None, ic=None, session=None):
+        """Forward only (no autograd): `_forward` with the normaliser / integration glue as two fused kernels
+        (bsms_sim_prologue / bsms_sim_epilogue) instead of ~15 element-wise launches.  `next_in` (may alias `node_in`)
+        receives the next autoregressive input where(mask == 0, ic, cat[pred, mesh_pos | type])
+        (utils/rollout_utils.py:57-62); `session`: ops.InferenceSession of an autoregressive caller."""
+        if not node_in.is_cuda:
+            raise _abi.BsmsError("BSMS_Simulator: the BSMS engine runs on the GPU only; there is no CPU fallback")
+        L, s = _abi.lib(), _stream()
+        node_in = node_in if (node_in.is_contiguous() and node_in.dtype == torch.float32) else node_in.contiguous().float()
+        mask = node_mask if (node_mask.is_contiguous() and node_mask.dtype == torch.float32) else node_mask.contiguous().float()
+        B, N, W = node_in.shape
+        C, p = W - 1 - self.pos_dim, self.pos_dim
+        R = B * N
+        if mask.numel() != R:
+            raise RuntimeError(f"node_mask has {mask.numel()} entries for {R} nodes")
+        ni, no = self._inputNormalizer, self._targetNormalizer
+        norm_in = torch.empty(B, N, C + 1, device=node_in.device, dtype=torch.float32)
+        pos = torch.empty(B, N, p, device=node_in.device, dtype=torch.float32)
+        _abi.check(L.bsms_sim_prologue(node_in.data_ptr(), R, C, p, ni._E_data.data_ptr(), ni._E_data_squared.data_ptr(),
+                                       ni.std_eps.data_ptr(), norm_in.data_ptr(), pos.data_ptr(), s), "bsms_sim_prologue")
+        x = self.encode(norm_in)
+        x = self.process(x, m_ids, m_gs, pos, session=session)
+        y = self.decode(x)
+        pred = torch.empty(B, N, C, device=node_in.device, dtype=torch.float32)
+        _abi.check(L.bsms_sim_epilogue(y.data_ptr(), node_in.data_ptr(), mask.data_ptr(), None, R, C, p, no._E_data.data_ptr(),
+                                       no._E_data_squared.data_ptr(), no.std_eps.data_ptr(), pred.data_ptr(),
+                                       None if next_in is None else next_in.data_ptr(), None if ic is None else ic.data_ptr(),
+                                       None, None, s), "bsms_sim_epilogue")
+        return pred
+
     def forward(self, data, consistent_mesh, warmup):  # model.py:166-208
         if consistent_mesh:
             node_in, node_tar, node_mask, m_gs, m_ids = data
@@ -124,6 +155,8 @@ class BSMS_Simulator(nn.Module):
             m_ids = [data[i].face for i in range(len(m_gs) - 1)]
         if warmup:
             return self._warmup(node_in, node_tar)
+        if not torch.is_grad_enabled() and node_in.is_cuda and not self.process.per_block:
+            return self._infer(m_ids, m_gs, node_in, node_mask)
         return self._forward(m_ids, m_gs, node_in, node_mask)
 
 

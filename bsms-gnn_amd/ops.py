@@ -23,7 +23,7 @@ import os
 from . import _abi
 from .graph import LevelPlan, plan_for
 
-__all__ = ["MLP", "GMP", "WeightedEdgeConv", "Unpool", "BSGMP", "scatter_sum", "degree"]
+__all__ = ["MLP", "GMP", "WeightedEdgeConv", "Unpool", "BSGMP", "InferenceSession", "scatter_sum", "degree"]
 
 
 # ------------------------------------------------------------------------------------ plumbing
@@ -502,7 +502,27 @@ class _BSGMPFunction(torch.autograd.Function):
         return (gh, None, None, None, None, *grads)
 
 
-def _bsgmp_infer(h, pos, plans, ews, hidden, params):
+class InferenceSession:
+    """State an autoregressive caller keeps between forward-only BSGMP calls (bsms_bsgmp_fwd_ex `reuse`): a PRIVATE work
+    buffer holding the weight packs and the coarse positions of the previous call.  Packs are reused while the
+    parameters are unchanged (data pointers + version counters); positions only if the caller declares them static
+    (rollout: mesh_pos never changes, utils/rollout_utils.py:46)."""
+
+    def __init__(self, static_pos=False):
+        self.static_pos, self.work, self.pkey, self.gkey = static_pos, None, None, None
+
+    def flags(self, params, plans, B, nbytes, device):
+        if self.work is None or self.work.numel() < nbytes or self.work.device != device:
+            self.work = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.pkey = self.gkey = None
+        pkey = tuple((q.data_ptr(), q._version) for q in params)
+        gkey = (tuple(id(q) for q in plans), B)
+        reuse = (1 if pkey == self.pkey and gkey == self.gkey else 0) | (2 if self.static_pos and gkey == self.gkey else 0)
+        self.pkey, self.gkey = pkey, gkey
+        return reuse
+
+
+def _bsgmp_infer(h, pos, plans, ews, hidden, params, session=None):
     B, _, D = h.shape
     p = pos.shape[-1]
     pos_bstride = pos.shape[-2] * p if pos.dim() == 3 else 0
@@ -511,10 +531,16 @@ def _bsgmp_infer(h, pos, plans, ews, hidden, params):
     pl, keep_pl = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in plans])
     ewp, keep_ew = _abi.ptr_array([e.data_ptr() for e in ews])
     out = torch.empty_like(h)
-    work = _workspace(h.device, L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden))
+    nbytes = L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden)
+    reuse = 0
+    if session is not None:
+        reuse = session.flags(params, plans, B, nbytes, h.device)
+        work = session.work
+    else:
+        work = _workspace(h.device, nbytes)
     pp, keep = _param_ptrs(params)
-    _abi.check(L.bsms_bsgmp_fwd(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
-                                out.data_ptr(), None, work.data_ptr(), _stream()), "bsms_bsgmp_fwd(inference)")
+    _abi.check(L.bsms_bsgmp_fwd_ex(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
+                                   out.data_ptr(), None, work.data_ptr(), reuse, _stream()), "bsms_bsgmp_fwd(inference)")
     return out
 
 
@@ -557,18 +583,29 @@ class BSGMP(nn.Module):
             plans[0]._ew_chain = (key, ews, plans)               # keeps the keyed plans alive -> ids stay unique
         return ews
 
-    def forward(self, h, m_ids, m_gs, pos):
+    def prepare(self, m_ids, m_gs, n0, device):
+        """(plans of levels 0..L-1 with their pools, cached edge weights, plan of the bottom level) of a hierarchy."""
+        plans, n_l = [], n0
+        for i in range(self.unet_depth):                     # plans first: they fix the level sizes
+            plans.append(plan_for(m_gs[i], n_l, m_ids[i]))
+            n_l = plans[-1].Nk
+        return plans, self._edge_weights(plans, m_ids, device), plan_for(m_gs[self.unet_depth], n_l)
+
+    def block_params(self):
+        """Parameters in the order of the bsms_bsgmp_* entries: down 0..L-1, bottom, up 0..L-1; node MLP then edge MLP."""
+        blocks = [*self.down_gmps, self.bottom_gmp, *self.up_gmps]
+        return [q for b in blocks for q in (*b.mlp_node.flat_params(), *b.mlp_edge.flat_params())]
+
+    def forward(self, h, m_ids, m_gs, pos, session=None):
+        """`session` (ops.InferenceSession, forward-only calls): reuse weight packs / coarse positions between calls."""
         if h.dim() not in (2, 3) or pos.dim() not in (2, 3):
             raise NotImplementedError("Only implemented for dim 2 and 3")
         h = _dev_f32(h, "BSGMP")
         pos = _dev_f32(pos, "BSGMP")
         L = self.unet_depth
-        skips, skip_pos, plans = [], [], []
-        n_l = h.shape[-2]
-        for i in range(L):                                   # plans first: they fix the level sizes
-            plans.append(plan_for(m_gs[i], n_l, m_ids[i]))
-            n_l = plans[-1].Nk
-        ews = self._edge_weights(plans, m_ids, pos.device)
+        skips, skip_pos = [], []
+        plans, ews, bottom_plan = self.prepare(m_ids, m_gs, h.shape[-2], pos.device)
+        n_l = bottom_plan.N
         if plans:
             _check_gmp_shapes("BSGMP", h, pos, plans[0], self.latent_dim, self.pos_dim)
         if not self.per_block:   # the whole U-Net in one library call (csrc/bsgmp.hip)
@@ -577,14 +614,13 @@ class BSGMP(nn.Module):
                 if pos.dim() == 3:
                     raise NotImplementedError("GMP: 2-D x with 3-D pos is not a layout of the reference")
                 h = h.unsqueeze(0)
-            all_plans = [*plans, plan_for(m_gs[L], n_l)]
-            blocks = [*self.down_gmps, self.bottom_gmp, *self.up_gmps]
-            params = [q for b in blocks for q in (*b.mlp_node.flat_params(), *b.mlp_edge.flat_params())]
+            all_plans = [*plans, bottom_plan]
+            params = self.block_params()
             hidden = self.bottom_gmp.hidden_layer
             if _needs_grad(h, *params):
                 y = _BSGMPFunction.apply(h, pos, all_plans, ews, hidden, *params)
             else:
-                y = _bsgmp_infer(h, pos, all_plans, ews, hidden, params)
+                y = _bsgmp_infer(h, pos, all_plans, ews, hidden, params, session)
             return y.squeeze(0) if squeeze else y
         for i in range(L):
             plan = plans[i]

@@ -1,42 +1,56 @@
 """Forward-only autoregressive rollout (reference: src/utils/rollout_utils.py:14-64, src/rollout.py:64-112).
 
-`rollout_one_traj` keeps the reference's signature.  The per-step forward runs in inference mode (the C
-ABI's `saved = NULL`: no activation is written) and, because a consistent mesh makes every step the same
-launch sequence on the same buffers, the step can be captured once into a HIP graph and replayed -- the
-B = 1 rollout launches ~150 few-microsecond kernels per step.  Measured on MI355X (airfoil, B = 1): eager
-563 steps/s, graph replay 493 steps/s -- the launches already keep the GPU busy, so eager is the default."""
+`rollout_one_traj` keeps the reference's signature.  A step is five calls -- prologue kernel, encoder, U-Net (C ABI
+`saved = NULL`: no activation is written; weight packs and coarse positions are reused from the previous step, they
+cannot change during a rollout), decoder, epilogue kernel -- and the epilogue writes the next input (the reference's
+`torch.cat` + `torch.where`) directly into the static input buffer.  Because a consistent mesh makes every step the
+same launch sequence on the same buffers, the step can also be captured once into a HIP graph and replayed.
+`rollout_batch` advances B trajectories of the same mesh at once (the reference rolls out one at a time); under data
+parallelism every rank takes its own slice of the trajectories -- there is nothing to exchange."""
 import torch
 
 
 class _Stepper:
-    """One rollout step `cur -> next` on static buffers, optionally replayed from a HIP graph."""
+    """One rollout step `cur -> next` on static buffers, optionally replayed from a HIP graph.  The whole step is
+    prologue kernel -> encode -> U-Net -> decode -> epilogue kernel: the epilogue writes the prediction AND the next
+    input (`torch.cat` + `torch.where` of the reference, rollout_utils.py:57-62) straight into the static input buffer;
+    the U-Net reuses its weight packs and the coarse positions from the previous step (ops.InferenceSession)."""
 
     def __init__(self, model, ic, node_mask, m_gs, m_ids, out_dim, use_graph):
-        self.model, self.ic, self.mask, self.m_gs, self.m_ids, self.c = model, ic, node_mask, m_gs, m_ids, out_dim
-        self.cur = ic.clone()                         # static input buffer
-        self.tail = ic[..., out_dim:].clone()         # mesh_pos + node_type never change (rollout_utils.py:46)
-        self.zero_tar = torch.zeros_like(ic)
+        from .ops import InferenceSession
+        self.model, self.c = model, out_dim
+        self.ic = ic.contiguous().float()
+        self.mask = node_mask.contiguous().float()
+        self.m_gs, self.m_ids = [g[0] for g in m_gs], [i[0] for i in m_ids]
+        self.cur = self.ic.clone()                    # static input buffer, rewritten in place by every step
+        self.session = InferenceSession(static_pos=True)
+        self.fused = ic.is_cuda and not model.process.per_block
         self.pred = None
         self.graph = None
-        if use_graph:
+        if use_graph and self.fused:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):             # warm-up outside capture: plans, workspaces, allocator
+            with torch.cuda.stream(side):             # warm-up outside capture: plans, workspaces, packs, coarse positions
                 for _ in range(2):
                     self._body()
             torch.cuda.current_stream().wait_stream(side)
-            self.cur.copy_(ic)
+            self.cur.copy_(self.ic)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._body()
-            self.cur.copy_(ic)
+            self.cur.copy_(self.ic)
 
     def _body(self):
-        pred = self.model((self.cur, self.zero_tar, self.mask, self.m_gs, self.m_ids), True, False)
-        nxt = torch.cat([pred, self.tail], dim=-1)
-        nxt = torch.where(self.mask == 0, self.ic, nxt)          # Dirichlet nodes keep their IC (rollout_utils.py:62)
+        if self.fused:
+            self.pred = self.model._infer(self.m_ids, self.m_gs, self.cur, self.mask, next_in=self.cur, ic=self.ic,
+                                          session=self.session)
+            return
+        zero = torch.zeros_like(self.ic[..., : self.c])
+        pred = self.model((self.cur, zero, self.mask, [g.unsqueeze(0) for g in self.m_gs], [i.unsqueeze(0) for i in self.m_ids]),
+                          True, False)
+        nxt = torch.cat([pred, self.cur[..., self.c:]], dim=-1)
+        self.cur.copy_(torch.where(self.mask == 0, self.ic, nxt))   # Dirichlet nodes keep their IC (rollout_utils.py:62)
         self.pred = pred
-        self.cur.copy_(nxt)
 
     def step(self):
         if self.graph is not None:
@@ -54,6 +68,17 @@ def rollout_one_traj(trainer, IC, results, node_mask, m_gs, m_ids, cfg=None, use
     stepper = _Stepper(model, IC, node_mask, m_gs, m_ids, results.shape[-1], use_graph and IC.is_cuda)
     for ti in range(results.shape[0]):
         results[ti] = stepper.step()[0]
+    return results
+
+
+@torch.no_grad()
+def rollout_batch(trainer, IC, results, node_mask, m_gs, m_ids, use_graph=False):
+    """B trajectories of one mesh advanced together: IC [B,N,C+p+1]; results [T-1,B,N,C] (filled and returned);
+    node_mask [B,N,1]; m_gs / m_ids as the consistent-mesh collate delivers them ([B,2,E_l] / [B,N_{l+1}])."""
+    model = trainer.model if hasattr(trainer, "model") else trainer
+    stepper = _Stepper(model, IC, node_mask, m_gs, m_ids, results.shape[-1], use_graph and IC.is_cuda)
+    for ti in range(results.shape[0]):
+        results[ti] = stepper.step()
     return results
 
 

@@ -1,0 +1,185 @@
+"""One training step of `BSMS_Simulator` -- forward, masked-RMSE loss, backward -- as a fixed sequence of C-ABI calls on
+static buffers, without autograd (reference: models/model.py:127-164, trainer/trainer.py:79-98,144-147).
+
+Why: the autograd mirror of the reference (model.py / ops.py) spends ~40 tiny element-wise launches per step on the
+normaliser and the loss, re-creates ~190 gradient views and pointer tables in Python every backward, and cannot be
+captured in a HIP graph.  Here the step is
+
+    bsms_sim_prologue -> bsms_mlp_fwd (encode) -> bsms_bsgmp_fwd (process) -> bsms_mlp_fwd (decode) -> bsms_sim_epilogue
+    [data parallel: all-reduce of the two loss sums]
+    bsms_sim_loss_bwd -> bsms_mlp_bwd (decode) -> bsms_bsgmp_bwd (process) -> bsms_mlp_bwd (encode)
+    [data parallel: all-reduce of the flat gradient buffer]
+
+with every weight gradient written straight into its slot of the flat gradient buffer (`GradBuckets.flat`), which the
+parameters' `.grad` alias.  Same kernels as the autograd path for everything but the glue: U-Net / MLP gradients are
+bit-identical to it, the loss and its gradient agree to fp32 round-off (tests/test_hip_training.py).  With
+`use_graph=True` the two halves are captured into HIP graphs and replayed (inputs are copied into static buffers)."""
+import torch
+import torch.distributed as dist
+
+from . import _abi
+from .ops import _param_ptrs, _stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class FusedStep:
+    def __init__(self, model, grads, group=None, use_graph=False):
+        from .model import BSMS_Simulator
+        if not isinstance(model, BSMS_Simulator):
+            raise TypeError("FusedStep drives a bsms_gnn_amd.BSMS_Simulator")
+        if model.process.per_block:
+            raise ValueError("FusedStep uses the one-call U-Net (BSGMP.per_block must be False)")
+        self.model, self.grads, self.group, self.use_graph = model, grads, group, use_graph
+        self._shape_key, self._graphs, self._ptr_guard = None, None, None
+        for p in grads.params:                      # .grad aliases the flat buffer once and for all
+            off, n = grads._slot[p]
+            p.grad = grads.flat[off:off + n].view_as(p)
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    @staticmethod
+    def supports(model):
+        from .model import BSMS_Simulator
+        return (isinstance(model, BSMS_Simulator) and not model.process.per_block
+                and all(p.requires_grad for p in [*model.encode.parameters(), *model.process.parameters(), *model.decode.parameters()]))
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _unpack(self, data, consistent):
+        if consistent:
+            node_in, tar, mask, m_gs, m_ids = data
+            m_gs, m_ids = [g[0] for g in m_gs], [i[0] for i in m_ids]
+        else:
+            node_in, tar, mask = data[0].x.unsqueeze(0), data[0].y.unsqueeze(0), data[0].mask.unsqueeze(0)
+            m_gs = [d.edge_index for d in data]
+            m_ids = [data[i].face for i in range(len(m_gs) - 1)]
+        f = lambda t: t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
+        return f(node_in), f(tar), f(mask), m_gs, m_ids
+
+    def _pointer_tables(self):
+        m = self.model
+        enc, proc, dec = m.encode.flat_params(), m.process.block_params(), m.decode.flat_params()
+        guard = (enc[0].data_ptr(), proc[-1].data_ptr(), dec[-1].data_ptr())
+        if guard != self._ptr_guard:                # parameters were re-pointed (optimizer flat buffer, .to(), load)
+            slot = lambda ps: [self.grads.flat[self.grads._slot[p][0]:].data_ptr() for p in ps]
+            self._tabs = {k: (_param_ptrs(ps), _abi.ptr_array(slot(ps))) for k, ps in (("enc", enc), ("proc", proc), ("dec", dec))}
+            self._ptr_guard = guard
+            self._graphs = None
+        return self._tabs
+
+    def _buffers(self, B, N, plans, dev):
+        m, L = self.model, _abi.lib()
+        C, p, D, H = m.cfg.out_dim, m.pos_dim, m.cfg.latent_dim, m.cfg.hidden_layer
+        key = (B, N, tuple(id(q) for q in plans), str(dev))
+        if key == self._shape_key:
+            return self._buf
+        R, depth = B * N, len(plans) - 1
+        pl, keep = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in plans])
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        u8 = lambda n: torch.empty(max(int(n), 1), device=dev, dtype=torch.uint8)
+        b = dict(R=R, pl=pl, pl_keep=keep, plans=plans, depth=depth,
+                 norm_in=f(R, C + 1), pos=f(R, p), h0=f(R, D), h1=f(R, D), norm_pred=f(R, C), pred=f(B, N, C),
+                 sums=f(2), loss=f(1), g_np=f(R, C), gh1=f(R, D), gh0=f(R, D),
+                 s_enc=u8(L.bsms_mlp_saved_bytes(R, C + 1, D, D, H)), s_dec=u8(L.bsms_mlp_saved_bytes(R, D, D, C, H)),
+                 s_proc=u8(L.bsms_bsgmp_saved_bytes(pl, depth, B, D, p, H)),
+                 work=u8(max(L.bsms_mlp_work_bytes(R, C + 1, D, D, H), L.bsms_mlp_work_bytes(R, D, D, C, H),
+                             L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, H), L.bsms_sim_work_bytes(R))),
+                 in_static=None)
+        self._shape_key, self._buf, self._graphs = key, b, None
+        return b
+
+    # ------------------------------------------------------------------------------------------------ the two halves
+    def _forward(self, b, node_in, tar, mask, ews, B, N):
+        m, L, s = self.model, _abi.lib(), _stream()
+        C, p, D, H = m.cfg.out_dim, m.pos_dim, m.cfg.latent_dim, m.cfg.hidden_layer
+        R, t = b["R"], self._tabs
+        work = b["work"]                      # owned scratch: the launches are ordered on one stream, also under capture
+        ni, no = m._inputNormalizer, m._targetNormalizer
+        ck = _abi.check
+        ck(L.bsms_sim_prologue(node_in.data_ptr(), R, C, p, ni._E_data.data_ptr(), ni._E_data_squared.data_ptr(),
+                               ni.std_eps.data_ptr(), b["norm_in"].data_ptr(), b["pos"].data_ptr(), s), "bsms_sim_prologue")
+        ck(L.bsms_mlp_fwd(b["norm_in"].data_ptr(), R, C + 1, D, D, H, 1, t["enc"][0][0], b["h0"].data_ptr(), b["s_enc"].data_ptr(),
+                          work.data_ptr(), s), "bsms_mlp_fwd(encode)")
+        ewp, keep = _abi.ptr_array([e.data_ptr() for e in ews])
+        ck(L.bsms_bsgmp_fwd(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), B, D, p, N * p, H, t["proc"][0][0],
+                            b["h1"].data_ptr(), b["s_proc"].data_ptr(), work.data_ptr(), s), "bsms_bsgmp_fwd")
+        ck(L.bsms_mlp_fwd(b["h1"].data_ptr(), R, D, D, C, H, 0, t["dec"][0][0], b["norm_pred"].data_ptr(), b["s_dec"].data_ptr(),
+                          work.data_ptr(), s), "bsms_mlp_fwd(decode)")
+        ck(L.bsms_sim_epilogue(b["norm_pred"].data_ptr(), node_in.data_ptr(), mask.data_ptr(), tar.data_ptr(), R, C, p,
+                               no._E_data.data_ptr(), no._E_data_squared.data_ptr(), no.std_eps.data_ptr(), b["pred"].data_ptr(),
+                               None, None, b["sums"].data_ptr(), work.data_ptr(), s), "bsms_sim_epilogue")
+
+    def _backward(self, b, tar, mask, ews, B, N):
+        m, L, s = self.model, _abi.lib(), _stream()
+        C, p, D, H = m.cfg.out_dim, m.pos_dim, m.cfg.latent_dim, m.cfg.hidden_layer
+        R, t = b["R"], self._tabs
+        work = b["work"]
+        no = m._targetNormalizer
+        ck = _abi.check
+        ck(L.bsms_sim_loss_bwd(b["pred"].data_ptr(), tar.data_ptr(), mask.data_ptr(), R, C, no._E_data.data_ptr(),
+                               no._E_data_squared.data_ptr(), no.std_eps.data_ptr(), b["sums"].data_ptr(), b["loss"].data_ptr(),
+                               b["g_np"].data_ptr(), s), "bsms_sim_loss_bwd")
+        ck(L.bsms_mlp_bwd(b["h1"].data_ptr(), b["g_np"].data_ptr(), R, D, D, C, H, 0, t["dec"][0][0], b["s_dec"].data_ptr(),
+                          work.data_ptr(), b["gh1"].data_ptr(), t["dec"][1][0], s), "bsms_mlp_bwd(decode)")
+        ewp, keep = _abi.ptr_array([e.data_ptr() for e in ews])
+        ck(L.bsms_bsgmp_bwd(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), b["gh1"].data_ptr(), B, D, p, N * p, H,
+                            t["proc"][0][0], b["s_proc"].data_ptr(), work.data_ptr(), b["gh0"].data_ptr(), t["proc"][1][0], s),
+           "bsms_bsgmp_bwd")
+        ck(L.bsms_mlp_bwd(b["norm_in"].data_ptr(), b["gh0"].data_ptr(), R, C + 1, D, D, H, 1, t["enc"][0][0], b["s_enc"].data_ptr(),
+                          work.data_ptr(), None, t["enc"][1][0], s), "bsms_mlp_bwd(encode)")
+
+    # ------------------------------------------------------------------------------------------------ the step
+    def __call__(self, data, consistent=True):
+        node_in, tar, mask, m_gs, m_ids = self._unpack(data, consistent)
+        if not node_in.is_cuda:
+            raise _abi.BsmsError("FusedStep: the BSMS engine runs on the GPU only; there is no CPU fallback")
+        B, N = node_in.shape[0], node_in.shape[1]
+        plans, ews, bottom = self.model.process.prepare(m_ids, m_gs, N, node_in.device)
+        plans = [*plans, bottom]
+        self._pointer_tables()
+        b = self._buffers(B, N, plans, node_in.device)
+        world = self._world()
+        if self.use_graph:
+            return self._replay(b, node_in, tar, mask, ews, B, N, world)
+        self._forward(b, node_in, tar, mask, ews, B, N)
+        if world > 1:
+            dist.all_reduce(b["sums"], op=dist.ReduceOp.SUM, group=self.group)
+        self._backward(b, tar, mask, ews, B, N)
+        if world > 1:
+            dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
+        return b["loss"][0]
+
+    def prediction(self):
+        """[B,N,C] prediction of the last step (a static buffer: clone it to keep it)."""
+        return self._buf["pred"]
+
+    def _replay(self, b, node_in, tar, mask, ews, B, N, world):
+        if b["in_static"] is None:
+            b["in_static"] = (torch.empty_like(node_in), torch.empty_like(tar), torch.empty_like(mask))
+            self._graphs = None
+        sn, st, sm = b["in_static"]
+        sn.copy_(node_in); st.copy_(tar); sm.copy_(mask)
+        if self._graphs is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):             # warm-up outside capture: workspaces, lazy kernel attributes, lanes
+                self._forward(b, sn, st, sm, ews, B, N)
+                self._backward(b, st, sm, ews, B, N)
+            torch.cuda.current_stream().wait_stream(side)
+            gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf):
+                self._forward(b, sn, st, sm, ews, B, N)
+            with torch.cuda.graph(gb):
+                self._backward(b, st, sm, ews, B, N)
+            self._graphs = (gf, gb, ews)              # the graphs hold raw pointers: keep what they point at alive
+        gf, gb, _ = self._graphs
+        gf.replay()
+        if world > 1:
+            dist.all_reduce(b["sums"], op=dist.ReduceOp.SUM, group=self.group)
+        gb.replay()
+        if world > 1:
+            dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
+        return b["loss"][0]

@@ -159,11 +159,43 @@ size_t bsms_bsgmp_work_bytes(const bsms_plan_t* const* plans, int L, int64_t B, 
 int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
                    int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                    const float* const* params, float* out, void* saved, void* work, bsms_stream_t stream);
+/* As bsms_bsgmp_fwd, with `reuse` for INFERENCE calls (saved == NULL) that pass the same `work` buffer as their previous
+ * call and let nothing else write to it: bit 0 = the weights are unchanged (skip the weight prepacks), bit 1 = pos and
+ * the mesh are unchanged (skip the coarse positions).  The autoregressive rollout (utils/rollout_utils.py:49-62: fixed
+ * weights, fixed mesh_pos) sets both from its second step on. */
+int bsms_bsgmp_fwd_ex(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                      int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                      const float* const* params, float* out, void* saved, void* work, int reuse, bsms_stream_t stream);
 int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
                    const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                    const float* const* params, const void* saved, void* work, float* grad_h,
                    float* const* grads, bsms_stream_t stream);
 
+
+/* ---------------------------------------------------------------- A10-A12: model glue + loss -
+ * BSMS_Simulator._forward (models/model.py:127-164) around encode / process / decode, the Normalizer arithmetic
+ * (utils/normalizer.py:40-52,80-90: fp64, cast to fp32) and the masked RMSE (trainer/trainer.py:96-97), fused:
+ *   bsms_sim_prologue  node_in [R, C+p+1] = [state(C) | mesh_pos(p) | node_type]  ->  norm_in [R, C+1] = normalised
+ *                      [state | node_type] (model.py:43-46,153), pos [R,p] contiguous (model.py:62)
+ *   bsms_sim_epilogue  norm_pred [R,C] (decoder output) -> pred = state + float(double(norm_pred) * std + mean) * mask
+ *                      (model.py:160-163).  Optional: `sums` (device float[2]) <- (sum se*mask, sum mask) of the loss
+ *                      against `target`; `next_in` [R, C+p+1] <- the next autoregressive input
+ *                      where(mask == 0, ic, cat[pred, mesh_pos | type]) (utils/rollout_utils.py:57-62; may alias node_in).
+ *   bsms_sim_loss_bwd  loss = sqrt(S / M / C) from `sums` (device; under data parallelism the caller all-reduces them
+ *                      first, so the loss is the exact global one) and d loss / d norm_pred.
+ * `mean`, `meansq`, `std_eps` are the DEVICE fp64 fields _E_data, _E_data_squared, std_eps of the reference's
+ * Normalizer (state_dict layout); std = max(nan_to_num(sqrt(meansq - mean^2)), std_eps).  mask is [R] (the [B,N,1]
+ * tensor of the reference, flat).  C <= 8.  Nothing here synchronises or reads device memory on the host. */
+size_t bsms_sim_work_bytes(int64_t R);
+int bsms_sim_prologue(const float* node_in, int64_t R, int64_t C, int64_t p, const double* mean, const double* meansq,
+                      const double* std_eps, float* norm_in, float* pos, bsms_stream_t stream);
+int bsms_sim_epilogue(const float* norm_pred, const float* node_in, const float* mask, const float* target /* nullable */,
+                      int64_t R, int64_t C, int64_t p, const double* mean, const double* meansq, const double* std_eps,
+                      float* pred, float* next_in /* nullable */, const float* ic /* nullable */, float* sums /* nullable */,
+                      void* work, bsms_stream_t stream);
+int bsms_sim_loss_bwd(const float* pred, const float* target, const float* mask, int64_t R, int64_t C, const double* mean,
+                      const double* meansq, const double* std_eps, const float* sums, float* loss_out /* nullable */,
+                      float* grad_norm_pred, bsms_stream_t stream);
 
 /* ---------------------------------------------------------------- hierarchy builder (host) ---
  * BistrideMultiLayerGraph (graph_wrappers/bsms_graph_wrapper.py:8-154 + graph_wrapper.py:67-134): the

@@ -11,10 +11,11 @@ mkdir -p $tmp/bsms-gnn_amd/csrc $tmp/include
 for f in $(git -C $root ls-tree --name-only $rev bsms-gnn_amd/csrc/); do git -C $root show $rev:$f > $tmp/$f; done
 cp $root/include/bsms_hip.h $tmp/include/
 cp $root/bsms-gnn_amd/csrc/hierarchy.hip $tmp/bsms-gnn_amd/csrc/
+[ -f $tmp/bsms-gnn_amd/csrc/sim.hip ] || cp $root/bsms-gnn_amd/csrc/sim.hip $tmp/bsms-gnn_amd/csrc/
 cd $tmp/bsms-gnn_amd/csrc
 objs=""
-for s in plan rowsum chain wgrad gmp bsgmp optim hierarchy; do
-  extra=""; [ $s = rowsum ] && extra="-ffp-contract=off"
+for s in $(ls *.hip | sed s/.hip//); do
+  extra=""; { [ $s = rowsum ] || [ $s = sim ]; } && extra="-ffp-contract=off"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra -c $s.hip -o $s.o &
   objs="$objs $s.o"
 done

@@ -426,6 +426,43 @@ def test_simulator_step_and_rollout_golden(eng, graphs):
         assert rel_err(res, torch.stack(frames)) < 2e-6, use_graph
 
 
+def test_fused_glue_kernels_equal_the_torch_glue(eng, graphs):
+    """bsms_sim_prologue / bsms_sim_epilogue (forward-only path of BSMS_Simulator) against the element-wise torch ops of
+    `_forward` (the op-for-op mirror of models/model.py:127-164 and utils/normalizer.py): the fp64 normaliser
+    arithmetic is reproduced exactly, so the predictions must be BIT-identical; then rollout_batch == B x rollout_one_traj."""
+    z = load_golden("sim")
+    es, ids = graphs.levels("del300")
+    sim = eng.BSMS_Simulator(ro.make_cfg(2, 32, 3, 3, 2))
+    sim.load_state_dict(z.state_dict())
+    sim = sim.cuda()
+    B = z.np("node_in").shape[0]
+    m_gs = [dev(e.unsqueeze(0).repeat(B, 1, 1)) for e in es]
+    m_ids = [dev(i.unsqueeze(0).repeat(B, 1)) for i in ids]
+    node_in, mask = dev(z.t("node_in")), dev(z.t("mask"))
+    with torch.no_grad():
+        fast = sim((node_in, None, mask, m_gs, m_ids), True, False)                  # -> _infer
+        slow = sim._forward([i[0] for i in m_ids], [g[0] for g in m_gs], node_in, mask)  # torch glue
+    assert torch.equal(fast, slow)
+    # degenerate statistics: zero variance -> std_eps, NaN variance -> nan_to_num
+    sim._inputNormalizer._E_data_squared.data = sim._inputNormalizer._E_data.data ** 2
+    sim._targetNormalizer._E_data_squared.data[0] = -1.0
+    with torch.no_grad():
+        fast = sim((node_in, None, mask, m_gs, m_ids), True, False)
+        slow = sim._forward([i[0] for i in m_ids], [g[0] for g in m_gs], node_in, mask)
+    assert torch.equal(fast, slow)
+    sim.load_state_dict(z.state_dict())
+    # batched rollout: three copies of one trajectory (one with a different IC) advance together
+    ic, rmask = dev(z.t("rollout_ic")), dev(z.t("rollout_mask"))
+    g1, i1 = [dev(e.unsqueeze(0)) for e in es], [dev(i.unsqueeze(0)) for i in ids]
+    one = eng.rollout_one_traj(sim, ic, torch.zeros(4, 300, 2, device="cuda"), rmask, g1, i1)
+    ic3 = torch.cat([ic, ic * 0.5, ic], 0)
+    res = eng.rollout_batch(sim, ic3, torch.zeros(4, 3, 300, 2, device="cuda"), rmask.repeat(3, 1, 1),
+                            [g.repeat(3, 1, 1) for g in g1], [i.repeat(3, 1) for i in i1])
+    assert torch.equal(res[:, 0], one) and torch.equal(res[:, 2], one) and not torch.equal(res[:, 1], one)
+    dead = rmask[0, :, 0] == 0
+    assert torch.equal(res[-1, 1][dead], (ic * 0.5)[0, :, :2][dead])               # Dirichlet nodes keep their IC
+
+
 def test_inference_mode_matches_training_forward(eng, graphs):
     """`saved` = NULL path (no activation stores) == the autograd forward, bit for bit."""
     es, _ = graphs.levels("del300")

@@ -138,3 +138,67 @@ def test_datapipe_to_trainer_end_to_end(eng, consistent):
     if consistent:
         assert built[-1] == built[1], "plans of a consistent mesh are built once (warm-up builds none, step 1 builds them)"
     assert float(tr.optimizer.grad_norm) > 0
+
+
+def _sim_batch(eng, graphs, B=2):
+    z = load_golden("sim")
+    es, ids = graphs.levels("del300")
+    m_gs = [e.unsqueeze(0).repeat(B, 1, 1).cuda() for e in es]
+    m_ids = [i.unsqueeze(0).repeat(B, 1).cuda() for i in ids]
+    return (z.t("node_in").cuda(), z.t("tar").cuda(), z.t("mask").cuda(), m_gs, m_ids)
+
+
+def test_fused_step_equals_autograd_step(eng, graphs):
+    """step.FusedStep (direct C-ABI calls, fused normaliser / loss kernels, gradients written into the flat buffer) against
+    the autograd mirror of the reference on the same model and batch: loss, prediction and every parameter gradient.
+    The U-Net / MLP kernels are the same; only the glue arithmetic is re-associated, hence 2e-6 instead of bit equality.
+    The HIP-graph replay of the fused step must be bit-identical to its eager form."""
+    import os
+    cfg = ro.make_cfg(2, 32, 3, 3, 2)
+    data = _sim_batch(eng, graphs)
+    torch.manual_seed(3)
+    sim = eng.BSMS_Simulator(cfg).cuda()
+    sim(data, True, True)
+    # autograd path
+    sim.zero_grad(set_to_none=True)
+    pred = sim(data, True, False)
+    loss = eng.masked_rmse(pred, data[1], data[2])
+    loss.backward()
+    want = {k: p.grad.clone() for k, p in sim.named_parameters() if p.grad is not None}
+    sim.zero_grad(set_to_none=True)
+    # fused path
+    grads = eng.GradBuckets(list(sim.parameters()))
+    step = eng.FusedStep(sim, grads)
+    got_loss = step(data, True)
+    assert abs(float(got_loss) - float(loss)) < 1e-6 * abs(float(loss))
+    assert rel_err(step.prediction().cpu(), pred.detach().cpu()) < 1e-6
+    assert set(k for k, p in sim.named_parameters() if p.grad is not None) == set(want)
+    for k, p in sim.named_parameters():
+        if p.requires_grad:
+            assert p.grad.data_ptr() >= grads.flat.data_ptr() and rel_err(p.grad.cpu(), want[k].cpu()) < 2e-6, k
+    eager = grads.flat.clone()
+    # a second batch shape / values through the same object, then the graph variant
+    gstep = eng.FusedStep(sim, grads, use_graph=True)
+    l1 = float(gstep(data, True))
+    assert torch.equal(grads.flat, eager) and abs(l1 - float(got_loss)) == 0.0
+    data2 = (data[0] * 1.01, data[1], data[2], data[3], data[4])
+    l2 = float(gstep(data2, True))                        # replay with new inputs copied into the static buffers
+    ref2 = float(step(data2, True))
+    assert l2 == ref2 and l2 != l1
+
+
+def test_data_parallel_uses_the_fused_step(eng, graphs):
+    """DataParallel.step_loss_backward == the autograd step (BSMS_FUSED_STEP=0 path), and the Trainer loop on top of it is
+    covered by test_trainer_iterations_follow_cpu_reference_loop."""
+    cfg = ro.make_cfg(2, 32, 3, 3, 2)
+    data = _sim_batch(eng, graphs)
+    torch.manual_seed(5)
+    sim = eng.BSMS_Simulator(cfg).cuda()
+    sim(data, True, True)
+    dp = eng.DataParallel(sim)
+    assert dp.fused is not None
+    l_f = float(dp.step_loss_backward(data, True))
+    g_f = dp.grads.flat.clone()
+    dp.fused = None
+    l_a = float(dp.step_loss_backward(data, True))
+    assert abs(l_f - l_a) < 1e-6 * abs(l_a) and rel_err(g_f.cpu(), dp.grads.flat.cpu()) < 2e-6
