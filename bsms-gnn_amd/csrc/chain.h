@@ -171,11 +171,17 @@ struct SmallWgradArgs {
   int D;
 };
 size_t small_wgrad_work_bytes(int D);
+size_t small_wgrad_work_bytes_rows(int D, int64_t workers);   // sized for the fused pair kernel: one block per 256 / (D/4) row workers
 int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s);
 
 // from rowsum.hip
 int rowsum_plan_order(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
 int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
 int rowsum_source_and_target(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD, hipStream_t s);
+int rowsum_source_target_fiber(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD,
+                               const float* fiber, int ld, int ncols, float* part, int64_t part_blocks, int* nwg, hipStream_t s);
+// wgrad.hip: partial blocks of the narrow weight gradients ([blocks][10][D] floats) and their fixed-order reduction
+int64_t small_wgrad_part_blocks(size_t work_bytes, int D);
+int launch_small_reduce(const SmallWgradArgs& a, const void* work, int nwg, hipStream_t s);
 
 }  // namespace bsms

@@ -102,6 +102,7 @@ struct GmpWork {
   float *gN[kMaxStages + 1], *daggr; // bwd
   float *gE[kMaxStages + 1], *dPs, *dPd;
   char *wg, *wg2, *sw;
+  size_t sw_bytes;
   size_t bytes;
 };
 GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H) {
@@ -375,19 +376,23 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     s2 = lane2->stream;
     scope2.lane = lane2;
   }
-  // gradient of the first edge Linear w.r.t. the two per-node projections
-  if ((rc = rowsum_source_and_target(plan, wk.gE[0], B, D, wk.dPs, wk.dPd, s))) return rc;   // one launch for both
-  // fiber columns of W0_edge and its bias
-  {
-    SmallWgradArgs a{};
-    a.G = wk.gE[0]; a.S = sv.e_fiber; a.S_cols = int(p + 1); a.S_ld = fiber_ld(p);   // the fiber rows the forward kept
-    a.p = (int)p;
-    a.out = ge[0]; a.os = 1; a.of = ldE0; a.colsum = ge[1];
-    a.R = B * E; a.D = (int)D;
-    if ((rc = launch_small_wgrad(a, wk.sw, s2))) return rc;
+  // gradient of the first edge Linear w.r.t. the two per-node projections -- and, in the same pass over gE[0], the
+  // partial sums of its fiber columns and bias (rowsum.hip: k_rowsum_pair_fiber); only their small reduction is left
+  SmallWgradArgs sw{};
+  sw.G = wk.gE[0]; sw.S = sv.e_fiber; sw.S_cols = int(p + 1); sw.S_ld = fiber_ld(p);   // the fiber rows the forward kept
+  sw.p = (int)p;
+  sw.out = ge[0]; sw.os = 1; sw.of = ldE0; sw.colsum = ge[1];
+  sw.R = B * E; sw.D = (int)D;
+  int nwg = 0;
+  if ((rc = rowsum_source_target_fiber(plan, wk.gE[0], B, D, wk.dPs, wk.dPd, sv.e_fiber, fiber_ld(p), int(p + 1),
+                                       reinterpret_cast<float*>(wk.sw), small_wgrad_part_blocks(wk.sw_bytes, (int)D), &nwg, s))) return rc;
+  if (nwg == 0) {   // shape not built into the fused kernel (D < 128, pos_dim > 3): separate passes
+    if ((rc = rowsum_source_and_target(plan, wk.gE[0], B, D, wk.dPs, wk.dPd, s))) return rc;
+    if ((rc = launch_small_wgrad(sw, wk.sw, s2))) return rc;
   }
   // x-columns of W0_edge (the two projections)
-  if (overlap2 && (rc = side_fork(lane2, s))) return rc;   // lane 2 additionally waits for dPs / dPd
+  if (overlap2 && (rc = side_fork(lane2, s))) return rc;   // lane 2 additionally waits for dPs / dPd (and the partials)
+  if (nwg > 0 && (rc = launch_small_reduce(sw, wk.sw, nwg, s2))) return rc;
   {
     WgradJob jobs[2];
     auto set = [&](WgradJob& j, const float* G, int col0) {

@@ -8,7 +8,7 @@
 // reproducible, and bit-identical to a sequential scatter_add_ (utils/basic.py:324-343).
 // Lanes run along the feature axis (16-byte loads, a 128-float row = one 512-byte burst of a
 // half-wave), so every HBM access is a fully used, coalesced row segment.
-#include "common.h"
+#include "chain.h"
 
 // hipcc defaults to -ffp-contract=fast, which would fuse the rounded product x*ew with the running sum
 // into one FMA; the reference rounds the product first (x[:, i] *= ew, then scatter_add_), so keep them apart.
@@ -126,6 +126,83 @@ __global__ __launch_bounds__(256) void k_rowsum_pair(RowSumArgs a0, RowSumArgs a
   const RowSumArgs& a = blockIdx.y ? a1 : a0;
   if (a.xidx) rowsum_body<LPR, false, false, DEEP, true, false>(a);
   else rowsum_body<LPR, false, false, DEEP, false, false>(a);
+}
+
+// ---- the two scatters of the first edge gradient + the narrow weight gradient of the first edge Linear, ONE launch.
+// blockIdx.y = 0: by source (transpose CSR, gathered rows), as k_rowsum_pair.  blockIdx.y = 1: by target -- the rows of
+// a target are contiguous in plan order, and while a lane streams them it also accumulates, for the fiber columns s
+// of the Linear (ops/basic.py:84-90), sum_e g[e][f] * fiber[e][s]: the gradient of those columns of W0 and (s = NS,
+// the plain row sum) of its bias.  The 256 / LPR workers of a workgroup are combined in fixed order through LDS and
+// written as one partial block; k_small_reduce (wgrad.hip) sums the blocks in fixed order.  This replaces a separate
+// pass over the whole [B,E,D] gradient (k_small_wgrad read it a third time: 128 MB at airfoil L0).
+template <int U, int NS>
+__device__ __forceinline__ void fiber_batch(const float* xcol, const float* frow, int D, int ld, int q, float4& acc,
+                                            float4 (&accf)[NS]) {
+  float4 v[U], f0[U], f1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    v[u] = *reinterpret_cast<const float4*>(xcol + int64_t(q + u) * D);
+    f0[u] = *reinterpret_cast<const float4*>(frow + int64_t(q + u) * ld);
+    if (NS > 4) f1[u] = *reinterpret_cast<const float4*>(frow + int64_t(q + u) * ld + 4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+    const float fs[8] = {f0[u].x, f0[u].y, f0[u].z, f0[u].w, NS > 4 ? f1[u].x : 0.f, NS > 4 ? f1[u].y : 0.f,
+                         NS > 4 ? f1[u].z : 0.f, NS > 4 ? f1[u].w : 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      accf[s].x = fmaf(v[u].x, fs[s], accf[s].x); accf[s].y = fmaf(v[u].y, fs[s], accf[s].y);
+      accf[s].z = fmaf(v[u].z, fs[s], accf[s].z); accf[s].w = fmaf(v[u].w, fs[s], accf[s].w);
+    }
+  }
+}
+
+constexpr int kSmallRows = 10;   // partial block = kSmallRows x D floats: rows 0..7 narrow products, 8 colsum(G), 9 colsum(S) (wgrad.hip)
+
+template <int LPR, int NS, bool DEEP>
+__global__ __launch_bounds__(256) void k_rowsum_pair_fiber(RowSumArgs a0, RowSumArgs a1, const float* fiber, int ld, float* part) {
+  if (blockIdx.y == 0) {
+    if (a0.xidx) rowsum_body<LPR, false, false, DEEP, true, false>(a0);
+    else rowsum_body<LPR, false, false, DEEP, false, false>(a0);
+    return;
+  }
+  __shared__ float4 red[256];
+  const RowSumArgs& a = a1;
+  const int64_t worker = (int64_t(blockIdx.x) * 256 + threadIdx.x) / LPR;
+  const int lane = threadIdx.x % LPR;
+  const bool live = worker < int64_t(a.B) * a.n_out;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) accf[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {   // D == 4 * LPR: one float4 column group per lane
+    const int b = int(worker / a.n_out), r = int(worker % a.n_out);
+    const int q0 = a.rowptr[r], q1 = a.rowptr[r + 1];
+    const float* xcol = a.x + b * a.x_bstride + lane * 4;
+    const float* frow = fiber + int64_t(b) * (a.x_bstride / a.D) * ld;
+    int q = q0;
+    if (DEEP)
+      for (; q + 16 <= q1; q += 16) fiber_batch<16, NS>(xcol, frow, a.D, ld, q, acc, accf);
+    for (; q + 4 <= q1; q += 4) fiber_batch<4, NS>(xcol, frow, a.D, ld, q, acc, accf);
+    for (; q < q1; ++q) fiber_batch<1, NS>(xcol, frow, a.D, ld, q, acc, accf);
+    *reinterpret_cast<float4*>(a.out + b * a.out_bstride + int64_t(r) * a.D + lane * 4) = acc;
+  }
+  float* blk = part + int64_t(blockIdx.x) * kSmallRows * a.D;
+#pragma unroll
+  for (int s = 0; s <= NS; ++s) {   // combine the workers of the workgroup in fixed order
+    red[threadIdx.x] = s < NS ? accf[s] : acc;
+    __syncthreads();
+    if (threadIdx.x < LPR) {
+      float4 v = red[threadIdx.x];
+      for (int w = 1; w < 256 / LPR; ++w) {
+        const float4 o = red[w * LPR + threadIdx.x];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(blk + (s < NS ? s : 8) * a.D + threadIdx.x * 4) = v;
+    }
+    __syncthreads();
+  }
 }
 
 // any D (positions: D = 2 or 3; 1-D sums): one thread per output element, slots in branch-free batches like rowsum_batch
@@ -296,6 +373,38 @@ int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, f
   a.x_bstride = p->E * D; a.out_bstride = p->N * D;
   a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
   return launch_rowsum(a, s);
+}
+// by source and by target at once + the narrow weight-gradient partials (see k_rowsum_pair_fiber); returns the number
+// of partial blocks in *nwg, or 0 there if this shape is not built (the caller then runs the separate kernels)
+int rowsum_source_target_fiber(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD,
+                               const float* fiber, int ld, int ncols, float* part, int64_t part_blocks, int* nwg, hipStream_t s) {
+  *nwg = 0;
+  const int64_t workers = B * p->N;
+  const int lpr = int(D / 4);
+  const int64_t blocks = ceil_div(workers * lpr, 256);
+  if (workers == 0 || (D != 128 && D != 256) || ncols < 1 || ncols > 4 || (ld & 3) || blocks > part_blocks) return BSMS_OK;
+  RowSumArgs a0{}, a1{};
+  a0.rowptr = p->t_rowptr; a0.xidx = p->t_pos;
+  a1.rowptr = p->rowptr;
+  a0.x = a1.x = x; a0.out = outS; a1.out = outD;
+  a0.x_bstride = a1.x_bstride = p->E * D; a0.out_bstride = a1.out_bstride = p->N * D;
+  a0.n_out = a1.n_out = (int32_t)p->N; a0.B = a1.B = (int32_t)B; a0.D = a1.D = (int32_t)D;
+  const dim3 grid((unsigned)blocks, 2);
+  const bool deep = workers * lpr < kDeepBelowThreads;
+#define BSMS_PF(L, NS)                                                                                                      \
+  do {                                                                                                                      \
+    if (deep) hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, true>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part);       \
+    else hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, false>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part);           \
+  } while (0)
+  if (D == 128) {
+    if (ncols == 1) BSMS_PF(32, 1); else if (ncols == 2) BSMS_PF(32, 2); else if (ncols == 3) BSMS_PF(32, 3); else BSMS_PF(32, 4);
+  } else {
+    if (ncols == 1) BSMS_PF(64, 1); else if (ncols == 2) BSMS_PF(64, 2); else if (ncols == 3) BSMS_PF(64, 3); else BSMS_PF(64, 4);
+  }
+#undef BSMS_PF
+  BSMS_LAUNCH_CHECK();
+  *nwg = (int)blocks;
+  return BSMS_OK;
 }
 // by source and by target at once: outS[b,i,:] = sum_{e: src(e)=i} x[b,slot(e),:], outD[b,j,:] = sum_{e: dst(e)=j} x[b,slot(e),:]
 int rowsum_source_and_target(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD, hipStream_t s) {

@@ -519,6 +519,18 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
 }
 
 size_t small_wgrad_work_bytes(int D) { return size_t(SW_WGS) * (SW_MAXS + 2) * D * sizeof(float); }
+size_t small_wgrad_work_bytes_rows(int D, int64_t workers) {
+  const int64_t blocks = std::max<int64_t>(SW_WGS, ceil_div(workers * (D / 4), 256));
+  return size_t(blocks) * (SW_MAXS + 2) * D * sizeof(float);
+}
+int64_t small_wgrad_part_blocks(size_t work_bytes, int D) { return int64_t(work_bytes / (size_t(SW_MAXS + 2) * D * sizeof(float))); }
+
+int launch_small_reduce(const SmallWgradArgs& a, const void* work, int nwg, hipStream_t s) {
+  hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)ceil_div((SW_MAXS + 2) * a.D, 8)), dim3(256), 0, s, a,
+                     reinterpret_cast<const float*>(work), nwg);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
 
 int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s) {
   BSMS_REQUIRE(a.S_cols >= 1 && a.S_cols <= SW_MAXS, BSMS_E_UNSUPPORTED, "small_wgrad: narrow width %d (max %d)", a.S_cols,
