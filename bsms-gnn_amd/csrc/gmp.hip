@@ -116,7 +116,8 @@ GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, i
   for (int l = 0; l <= H; ++l) w.gE[l] = c.take(re * D);
   w.wg = c.take_bytes(wgrad_work_bytes((int)D, 0));
   w.wg2 = c.take_bytes(wgrad_work_bytes((int)D, 0));   // second split-K area: two wgrad launches run concurrently
-  w.sw = c.take_bytes(small_wgrad_work_bytes((int)D));
+  w.sw_bytes = small_wgrad_work_bytes_rows((int)D, B * N);   // one partial block per workgroup of the fused scatter kernel
+  w.sw = c.take_bytes(w.sw_bytes);
   w.bytes = c.off;
   return w;
 }
