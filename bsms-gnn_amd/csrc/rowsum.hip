@@ -162,40 +162,47 @@ __device__ __forceinline__ void fiber_batch(const float* xcol, const float* frow
 constexpr int kSmallRows = 10;   // partial block = kSmallRows x D floats: rows 0..7 narrow products, 8 colsum(G), 9 colsum(S) (wgrad.hip)
 
 template <int LPR, int NS, bool DEEP>
-__global__ __launch_bounds__(256) void k_rowsum_pair_fiber(RowSumArgs a0, RowSumArgs a1, const float* fiber, int ld, float* part) {
-  if (blockIdx.y == 0) {
+__global__ __launch_bounds__(256) void k_rowsum_pair_fiber(RowSumArgs a0, RowSumArgs a1, const float* fiber, int ld, float* part,
+                                                          int nsrc_blocks) {
+  // blocks [0, nsrc_blocks): by source, one worker per output row (as k_rowsum_pair); the remaining gridDim.x -
+  // nsrc_blocks blocks: by target, workers stride over the rows so that the number of partial blocks stays small
+  if (int(blockIdx.x) < nsrc_blocks) {
     if (a0.xidx) rowsum_body<LPR, false, false, DEEP, true, false>(a0);
     else rowsum_body<LPR, false, false, DEEP, false, false>(a0);
     return;
   }
   __shared__ float4 red[256];
   const RowSumArgs& a = a1;
-  const int64_t worker = (int64_t(blockIdx.x) * 256 + threadIdx.x) / LPR;
+  const int ntgt = int(gridDim.x) - nsrc_blocks, j = int(blockIdx.x) - nsrc_blocks;
+  constexpr int WPB = 256 / LPR;   // workers per block
   const int lane = threadIdx.x % LPR;
-  const bool live = worker < int64_t(a.B) * a.n_out;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accf[NS];
+  const int64_t total = int64_t(a.B) * a.n_out;
+  float4 accs = make_float4(0.f, 0.f, 0.f, 0.f), accf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) accf[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) {   // D == 4 * LPR: one float4 column group per lane
+  for (int64_t worker = int64_t(j) * WPB + threadIdx.x / LPR; worker < total; worker += int64_t(ntgt) * WPB) {
+    // D == 4 * LPR: one float4 column group per lane
     const int b = int(worker / a.n_out), r = int(worker % a.n_out);
     const int q0 = a.rowptr[r], q1 = a.rowptr[r + 1];
     const float* xcol = a.x + b * a.x_bstride + lane * 4;
     const float* frow = fiber + int64_t(b) * (a.x_bstride / a.D) * ld;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int q = q0;
     if (DEEP)
       for (; q + 16 <= q1; q += 16) fiber_batch<16, NS>(xcol, frow, a.D, ld, q, acc, accf);
     for (; q + 4 <= q1; q += 4) fiber_batch<4, NS>(xcol, frow, a.D, ld, q, acc, accf);
     for (; q < q1; ++q) fiber_batch<1, NS>(xcol, frow, a.D, ld, q, acc, accf);
     *reinterpret_cast<float4*>(a.out + b * a.out_bstride + int64_t(r) * a.D + lane * 4) = acc;
+    accs.x += acc.x; accs.y += acc.y; accs.z += acc.z; accs.w += acc.w;
   }
-  float* blk = part + int64_t(blockIdx.x) * kSmallRows * a.D;
+  float* blk = part + int64_t(j) * kSmallRows * a.D;
 #pragma unroll
   for (int s = 0; s <= NS; ++s) {   // combine the workers of the workgroup in fixed order
-    red[threadIdx.x] = s < NS ? accf[s] : acc;
+    red[threadIdx.x] = s < NS ? accf[s] : accs;
     __syncthreads();
     if (threadIdx.x < LPR) {
       float4 v = red[threadIdx.x];
-      for (int w = 1; w < 256 / LPR; ++w) {
+      for (int w = 1; w < WPB; ++w) {
         const float4 o = red[w * LPR + threadIdx.x];
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
       }
@@ -382,19 +389,21 @@ int rowsum_source_target_fiber(const bsms_plan* p, const float* x, int64_t B, in
   const int64_t workers = B * p->N;
   const int lpr = int(D / 4);
   const int64_t blocks = ceil_div(workers * lpr, 256);
-  if (workers == 0 || (D != 128 && D != 256) || ncols < 1 || ncols > 4 || (ld & 3) || blocks > part_blocks) return BSMS_OK;
+  const int64_t tgt_blocks = std::min<int64_t>(blocks, std::min<int64_t>(part_blocks, 1024));   // = partial blocks to reduce
+  if (workers == 0 || (D != 128 && D != 256) || ncols < 1 || ncols > 4 || (ld & 3) || tgt_blocks < 1) return BSMS_OK;
   RowSumArgs a0{}, a1{};
   a0.rowptr = p->t_rowptr; a0.xidx = p->t_pos;
   a1.rowptr = p->rowptr;
   a0.x = a1.x = x; a0.out = outS; a1.out = outD;
   a0.x_bstride = a1.x_bstride = p->E * D; a0.out_bstride = a1.out_bstride = p->N * D;
   a0.n_out = a1.n_out = (int32_t)p->N; a0.B = a1.B = (int32_t)B; a0.D = a1.D = (int32_t)D;
-  const dim3 grid((unsigned)blocks, 2);
+  const dim3 grid((unsigned)(blocks + tgt_blocks));
   const bool deep = workers * lpr < kDeepBelowThreads;
-#define BSMS_PF(L, NS)                                                                                                      \
-  do {                                                                                                                      \
-    if (deep) hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, true>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part);       \
-    else hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, false>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part);           \
+  const int nsrc = (int)blocks;
+#define BSMS_PF(L, NS)                                                                                                          \
+  do {                                                                                                                          \
+    if (deep) hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, true>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part, nsrc);     \
+    else hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, false>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part, nsrc);         \
   } while (0)
   if (D == 128) {
     if (ncols == 1) BSMS_PF(32, 1); else if (ncols == 2) BSMS_PF(32, 2); else if (ncols == 3) BSMS_PF(32, 3); else BSMS_PF(32, 4);
@@ -403,7 +412,7 @@ int rowsum_source_target_fiber(const bsms_plan* p, const float* x, int64_t B, in
   }
 #undef BSMS_PF
   BSMS_LAUNCH_CHECK();
-  *nwg = (int)blocks;
+  *nwg = (int)tgt_blocks;
   return BSMS_OK;
 }
 // by source and by target at once: outS[b,i,:] = sum_{e: src(e)=i} x[b,slot(e),:], outD[b,j,:] = sum_{e: dst(e)=j} x[b,slot(e),:]

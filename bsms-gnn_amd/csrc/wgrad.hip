@@ -520,8 +520,8 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
 
 size_t small_wgrad_work_bytes(int D) { return size_t(SW_WGS) * (SW_MAXS + 2) * D * sizeof(float); }
 size_t small_wgrad_work_bytes_rows(int D, int64_t workers) {
-  const int64_t blocks = std::max<int64_t>(SW_WGS, ceil_div(workers * (D / 4), 256));
-  return size_t(blocks) * (SW_MAXS + 2) * D * sizeof(float);
+  (void)workers;   // the fused scatter kernel strides its workers over the rows: at most 1024 partial blocks
+  return size_t(std::max(SW_WGS, 1024)) * (SW_MAXS + 2) * D * sizeof(float);
 }
 int64_t small_wgrad_part_blocks(size_t work_bytes, int D) { return int64_t(work_bytes / (size_t(SW_MAXS + 2) * D * sizeof(float))); }
 
