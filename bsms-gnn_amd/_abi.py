@@ -25,6 +25,7 @@ SIGNATURES = {
     "bsms_plan_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bsms_segment_sum_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "bsms_segment_sum_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
+    "bsms_segment_sum_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "bsms_cal_ew": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bsms_edge_conv": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "bsms_scatter_rows": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
@@ -46,6 +47,11 @@ SIGNATURES = {
                                c_void_p, c_void_p]),
     "bsms_bsgmp_fwd_ex": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p, c_void_p,
                                   c_void_p, c_int, c_void_p]),
+    "bsms_bsgmp_saved_bytes_p": (c_size_t, [PP, c_int, c_i64, c_i64, c_i64, c_int, c_int]),
+    "bsms_bsgmp_fwd_p": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_int, c_void_p]),
+    "bsms_bsgmp_bwd_p": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
+                                 c_void_p, c_void_p, PP, c_int, c_void_p]),
     "bsms_bsgmp_bwd": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
                                c_void_p, c_void_p, PP, c_void_p]),
     "bsms_sim_work_bytes": (c_size_t, [c_i64]),

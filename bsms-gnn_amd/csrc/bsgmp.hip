@@ -23,6 +23,7 @@ struct Shape {
   int L;
   int64_t B, D, p, N[kMaxLevels + 1], E[kMaxLevels + 1];
   int H;
+  int prec = BSMS_F32;
 };
 
 struct Carve {
@@ -49,11 +50,11 @@ struct Saved {
 Saved carve_saved(void* base, const Shape& s, bool training) {
   Carve c(base);
   Saved v{};
-  for (int i = 0; i < s.L; ++i) v.gmp[i] = training ? c.bytes(bsms_gmp_saved_bytes(s.B, s.N[i], s.E[i], s.D, s.H)) : nullptr;
-  v.gmp[s.L] = training ? c.bytes(bsms_gmp_saved_bytes(s.B, s.N[s.L], s.E[s.L], s.D, s.H)) : nullptr;
+  for (int i = 0; i < s.L; ++i) v.gmp[i] = training ? c.bytes(gmp_saved_bytes_p(s.B, s.N[i], s.E[i], s.D, s.H, s.prec)) : nullptr;
+  v.gmp[s.L] = training ? c.bytes(gmp_saved_bytes_p(s.B, s.N[s.L], s.E[s.L], s.D, s.H, s.prec)) : nullptr;
   for (int i = 0; i < s.L; ++i) {
     const int d = s.L - 1 - i;
-    v.gmp[s.L + 1 + i] = training ? c.bytes(bsms_gmp_saved_bytes(s.B, s.N[d], s.E[d], s.D, s.H)) : nullptr;
+    v.gmp[s.L + 1 + i] = training ? c.bytes(gmp_saved_bytes_p(s.B, s.N[d], s.E[d], s.D, s.H, s.prec)) : nullptr;
   }
   for (int i = 1; i <= s.L; ++i) {
     v.hin[i] = c.floats(size_t(s.B) * s.N[i] * s.D);
@@ -109,8 +110,13 @@ inline float* const* block(float* const* grads, int k, int H) { return grads + s
 }  // namespace
 
 extern "C" size_t bsms_bsgmp_saved_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden) {
+  return bsms_bsgmp_saved_bytes_p(plans, L, B, D, p, hidden, BSMS_F32);
+}
+extern "C" size_t bsms_bsgmp_saved_bytes_p(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden,
+                                           int precision) {
   Shape s;
   if (make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_saved_bytes")) return 0;
+  s.prec = precision;
   return carve_saved(nullptr, s, true).bytes;
 }
 extern "C" size_t bsms_bsgmp_work_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden) {
@@ -123,15 +129,24 @@ extern "C" size_t bsms_bsgmp_work_bytes(const bsms_plan_t* const* plans, int L, 
 extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
                               int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                               const float* const* params, float* out, void* saved, void* work, bsms_stream_t stream) {
-  return bsms_bsgmp_fwd_ex(plans, ew, L, h, pos, B, D, p, pos_batch_stride, hidden, params, out, saved, work, 0, stream);
+  return bsms_bsgmp_fwd_p(plans, ew, L, h, pos, B, D, p, pos_batch_stride, hidden, params, out, saved, work, 0, BSMS_F32, stream);
 }
 
 extern "C" int bsms_bsgmp_fwd_ex(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
                                  int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                                  const float* const* params, float* out, void* saved, void* work, int reuse, bsms_stream_t stream) {
+  return bsms_bsgmp_fwd_p(plans, ew, L, h, pos, B, D, p, pos_batch_stride, hidden, params, out, saved, work, reuse, BSMS_F32, stream);
+}
+
+extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                                int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                                const float* const* params, float* out, void* saved, void* work, int reuse, int precision,
+                                bsms_stream_t stream) {
   Shape s;
   int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_fwd");
   if (rc) return rc;
+  BSMS_REQUIRE(precision == BSMS_F32 || precision == BSMS_BF16, BSMS_E_UNSUPPORTED, "bsgmp_fwd: precision %d", precision);
+  s.prec = precision;
   BSMS_REQUIRE(h && pos && params && out && work && (ew || L == 0), BSMS_E_INVALID_ARG, "bsgmp_fwd: null argument");
   hipStream_t st = as_stream(stream);
   const bool training = saved != nullptr;
@@ -163,14 +178,14 @@ extern "C" int bsms_bsgmp_fwd_ex(const bsms_plan_t* const* plans, const float* c
       if ((rc = side_lane(&lane0, 0)) || (rc = side_fork(lane0, st))) return rc;
       for (int k = 1; k <= 2 * L; ++k) {
         const int lv = level_of_block(k, L);
-        if ((rc = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream))) return rc;
+        if ((rc = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream, precision))) return rc;
       }
     }
   }
   const float* hi = h;
   for (int i = 0; i < L; ++i) {
     if ((rc = gmp_fwd_core(plans[i], hi, pos_l[i], B, D, p, pstride_l[i], hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp,
-                           packs_of(i), i == 0 && !packs_ok, nullptr, st))) return rc;
+                           packs_of(i), i == 0 && !packs_ok, nullptr, st, precision))) return rc;
     if (i == 0 && ((lane && (rc = side_join(lane, st))) || (lane0 && (rc = side_join(lane0, st))))) return rc;
     // restrict the features to the kept nodes (ops/BSMS.py:74, 79-83)
     if ((rc = bsms_edge_conv(plans[i], w.skip[i], B, D, ew[i], 1, 1, v.hin[i + 1], stream))) return rc;
@@ -180,14 +195,14 @@ extern "C" int bsms_bsgmp_fwd_ex(const bsms_plan_t* const* plans, const float* c
   const int64_t pstride = pstride_l[L];
   float* cur = (L == 0) ? out : w.a[0];
   if ((rc = gmp_fwd_core(plans[L], hi, pi, B, D, p, pstride, hidden, block(params, L, hidden), cur, v.gmp[L], w.gmp, packs_of(L),
-                         L == 0 && !packs_ok, nullptr, st))) return rc;
+                         L == 0 && !packs_ok, nullptr, st, precision))) return rc;
   for (int i = 0; i < L; ++i) {
     const int d = L - 1 - i;
     if ((rc = bsms_edge_conv(plans[d], cur, B, D, ew[d], 0, 1, v.upin[d], stream))) return rc;   // prolong (BSMS.py:98-100)
     // up block + skip connection (BSMS.py:101-102): the node chain's epilogue adds s_d after its own residual
     float* nxt = (d == 0) ? out : w.a[(i + 1) & 1];
     if ((rc = gmp_fwd_core(plans[d], v.upin[d], pos_l[d], B, D, p, pstride_l[d], hidden, block(params, L + 1 + i, hidden), nxt,
-                           v.gmp[L + 1 + i], w.gmp, packs_of(L + 1 + i), false, w.skip[d], st))) return rc;
+                           v.gmp[L + 1 + i], w.gmp, packs_of(L + 1 + i), false, w.skip[d], st, precision))) return rc;
     cur = nxt;
   }
   return BSMS_OK;
@@ -197,9 +212,19 @@ extern "C" int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* cons
                               const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                               const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
                               bsms_stream_t stream) {
+  return bsms_bsgmp_bwd_p(plans, ew, L, h, pos, grad_out, B, D, p, pos_batch_stride, hidden, params, saved, work, grad_h, grads,
+                          BSMS_F32, stream);
+}
+
+extern "C" int bsms_bsgmp_bwd_p(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                                const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                                const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
+                                int precision, bsms_stream_t stream) {
   Shape s;
   int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_bwd");
   if (rc) return rc;
+  BSMS_REQUIRE(precision == BSMS_F32 || precision == BSMS_BF16, BSMS_E_UNSUPPORTED, "bsgmp_bwd: precision %d", precision);
+  s.prec = precision;
   BSMS_REQUIRE(h && pos && grad_out && params && saved && work && grad_h && grads && (ew || L == 0), BSMS_E_INVALID_ARG,
                "bsgmp_bwd: null argument");
   hipStream_t st = as_stream(stream);
@@ -229,7 +254,7 @@ extern "C" int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* cons
     ++nblk;
     marked[slot] = true;
     return gmp_bwd_core(plans[level], x, pos_l[level], g_in, B, D, p, pstride_l[level], hidden, block(params, k, hidden), v.gmp[k],
-                        slot ? w.gmp_b : w.gmp, gx, block(grads, k, hidden), slot, st);
+                        slot ? w.gmp_b : w.gmp, gx, block(grads, k, hidden), slot, st, precision);
   };
   // up path, last block first.  The gradient reaching level d is both the up block's grad_out and the gradient of
   // the skip connection s_d: it stays in w.skip[d] until the down path picks it up.

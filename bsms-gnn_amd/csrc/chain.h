@@ -36,6 +36,9 @@ constexpr int kComputeWaves = 4;                       // compute waves per work
 constexpr int kTileRows = kComputeWaves * 16;          // rows of x per workgroup
 constexpr int kChainThreads = (kComputeWaves + 1) * 64;  // + 1 loader wave
 constexpr int kChunkHdrFloats = 256;                     // 1 KB chunk header (bias)
+// Precision of the EDGE-level tensors of a GMP block (include/bsms_hip.h: bsms_precision).  BF16: the saved edge
+// activations, the messages y and the edge layer gradients are stored as bf16 and the edge MLP's products take bf16
+// operands (weights rounded once per call) with fp32 accumulation; everything at node level stays fp32.
 // A saved activation [rows, D] is followed by its ReLU sign bits, one bit per element packed per (row, lane group):
 // the backward chain masks gradients from 16 bytes per row instead of re-reading 4 D bytes.
 constexpr size_t mask_words_per_row(int64_t D) { return size_t(4) * (D <= 128 ? 1 : D / 128); }
@@ -85,6 +88,7 @@ struct ChainFwdArgs {
   const float* bout;  // OUT_SMALL: [C]
   int C;
   unsigned long long* timing;  // experiments only: per-workgroup s_memtime stamps (16 slots), null in production
+  int bf16;           // bf16 precision (IN_EDGE / OUT_LN only): bf16 MFMA operands, saved activations and y stored as bf16
   int store_mode;     // saved-activation stores: 0 plain, 1 non-temporal (keeps L2 for weights / gathered rows)
   int out_mode;       // same for the final output y
   // ---- filled by launch_chain_fwd: weight packs in execution order for the loader wave
@@ -112,6 +116,7 @@ struct ChainBwdArgs {
   float *dx, *dx2;
   const float* dres;  // added to dx (residual branch), nullable
   int store_mode;     // layer-gradient stores: 0 plain, 1 non-temporal
+  int bf16;           // bf16 precision (G_EDGE_LN / F_NONE only): yln is bf16, layer gradients are stored as bf16
   // ---- filled by launch_chain_bwd: weight packs in execution order for the loader wave
   int nseq;
   const float4* wseq[kMaxStages + 2];
@@ -127,6 +132,7 @@ struct PackDesc {
   int N, K;  // logical matrix M[n][k], n < N (outputs), k < K (reduction)
   int kind;  // FRAG: M[n][k] = W[row0+n][col0+k]; FRAG_T: M[n][k] = W[row0+k][col0+n];   (N == K, multiple of 32)
              // TRANSPOSE: dst[k*N+n] = W[row0+n][col0+k] (plain, for the small VALU layers)
+  int bf16;  // FRAG kinds: plane 0 = the weight rounded to bf16, planes 1 / 2 empty (bf16 precision)
 };
 constexpr int kMaxPack = 40;
 struct PackTable {
@@ -146,6 +152,7 @@ struct WgradJob {
   float* db;       // db[n] = sum_r G[r][n]   (nullable)
   int64_t R;
   int ldg, lda, ldw, col0;
+  int bf16;        // G and A are bf16 tensors (ld in elements): one bf16 product instead of the six split products
 };
 constexpr int kMaxWgradJobs = 20;
 size_t wgrad_work_bytes(int D, int njobs);
@@ -179,7 +186,9 @@ int rowsum_plan_order(const bsms_plan* p, const float* x, int64_t B, int64_t D, 
 int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
 int rowsum_source_and_target(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD, hipStream_t s);
 int rowsum_source_target_fiber(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD,
-                               const float* fiber, int ld, int ncols, float* part, int64_t part_blocks, int* nwg, hipStream_t s);
+                               const float* fiber, int ld, int ncols, float* part, int64_t part_blocks, int* nwg, hipStream_t s,
+                               bool x_bf16 = false);
+int rowsum_plan_order_bf16(const bsms_plan* p, const float* x_bf16, int64_t B, int64_t D, float* out, hipStream_t s);
 // wgrad.hip: partial blocks of the narrow weight gradients ([blocks][10][D] floats) and their fixed-order reduction
 int64_t small_wgrad_part_blocks(size_t work_bytes, int D);
 int launch_small_reduce(const SmallWgradArgs& a, const void* work, int nwg, hipStream_t s);

@@ -10,6 +10,38 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // Register layout ("chain layout", see chain.h): a wave owns 16 rows; lane l <-> row (l & 15), group g = l >> 4.
 // For every 16-feature block t the lane holds features 16 t + 4 g + {0,1,2,3} as one f32x4.
 
+// ---- bf16 storage (BSMS_BF16 precision: edge-level tensors are kept as bf16 in HBM, chain.h)
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// rows of a bf16 tensor [R, D]: lane (row, g) owns features 16 t + 4 g + {0..3} = 8 bytes per 16-feature block
+template <int NB>
+__device__ __forceinline__ void load_rows_bf16(f32x4 (&v)[NB], const void* base, int64_t row, int g) {
+  const uint2* p = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + row * (NB * 16) + 4 * g);
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const uint2 u = p[4 * t];   // 16 features = 32 bytes = 4 uint2 further
+    v[t] = f32x4{bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y)};
+  }
+}
+template <int NB>
+__device__ __forceinline__ void store_block_bf16(const f32x4 (&v)[NB], void* base, int64_t row, int g, int t) {
+  uint2* p = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + row * (NB * 16) + 4 * g);
+  p[4 * t] = make_uint2(pk_bf16(v[t][0], v[t][1]), pk_bf16(v[t][2], v[t][3]));
+}
+template <int NB>
+__device__ __forceinline__ void store_rows_bf16(const f32x4 (&v)[NB], void* base, int64_t off, int g) {
+  if (!base || off < 0) return;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) store_block_bf16<NB>(v, base, off / (NB * 16), g, t);
+}
+
 // ---------------------------------------------------------------------------------- prepack ----
 // exact three-way bf16 split by truncation: x = hi + mid + lo, each piece's low 16 bits are zero
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
@@ -52,7 +84,12 @@ __global__ __launch_bounds__(256) void k_prepack(PackTable tab) {
       const float x = (d.kind == PACK_FRAG_T) ? d.W[int64_t(d.row0 + k) * d.ld + d.col0 + n]
                                               : d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
       unsigned hi, mid, lo;
-      split3(x, hi, mid, lo);
+      if (d.bf16) {   // bf16 precision: the weight IS its bf16 rounding (nearest even); planes 1 and 2 stay empty
+        hi = pk_bf16(x, 0.f) << 16;
+        mid = lo = 0u;
+      } else {
+        split3(x, hi, mid, lo);
+      }
       piece[e] = plane == 0 ? hi : plane == 1 ? mid : lo;
     }
     dst[o] = (piece[0] >> 16) | (piece[1] & 0xffff0000u);
@@ -136,11 +173,12 @@ __device__ __forceinline__ void store_pair_stream(const f32x4 (&v)[NB], float* b
 template <int NB>
 constexpr int mask_words() { return NB <= 8 ? 1 : NB / 8; }
 
-template <int NB>
+// `BF`: the activation block in front of the bits is bf16 (R * D * 2 bytes) instead of fp32
+template <int NB, bool BF = false>
 __device__ __forceinline__ void store_mask_bits(const f32x4 (&v)[NB], float* act_base, int64_t R, int64_t off, int g) {
   if (!act_base || off < 0) return;
   constexpr int D = NB * 16, W = mask_words<NB>();
-  unsigned* bits = reinterpret_cast<unsigned*>(act_base + R * D) + (off / D) * (4 * W) + g * W;
+  unsigned* bits = reinterpret_cast<unsigned*>(act_base + (BF ? R * D / 2 : R * D)) + (off / D) * (4 * W) + g * W;
 #pragma unroll
   for (int w = 0; w < W; ++w) {
     unsigned m = 0;
@@ -267,6 +305,13 @@ __device__ __forceinline__ void split_block(const f32x4 (&act)[NB], int kb2, u32
   }
 }
 
+// bf16 precision: the activation IS its bf16 rounding -- one plane, no residuals
+template <int NB>
+__device__ __forceinline__ void round_block(const f32x4 (&act)[NB], int kb2, u32x4& bh) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) bh[v] = pk_bf16(act[2 * kb2 + (v >> 1)][2 * (v & 1)], act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1]);
+}
+
 __device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -276,12 +321,49 @@ __device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
 // header of the stage's first chunk instead of accumulating onto the caller's acc.
 // `store_base` (nullable, uniform) + `store_off`: HBM tensor / this lane's row offset that receives `act`; issued
 // right after the split so the store has the whole stage to drain.  All compute waves of the workgroup must call this together.
-template <int NB, bool TIMED = false>
+// BF (bf16 precision, chain.h): operands are the bf16 roundings of `act` and of the weights (plane 0 of the pack holds
+// the rounded weight, the other planes are unused), ONE product per fragment pair; `store_base` receives bf16 rows.
+template <int NB, bool TIMED = false, bool BF = false>
 __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
                                            bool from_header, float* store_base = nullptr, int64_t store_off = -1,
                                            int store_mode = 0, int64_t mask_rows = 0,
                                            unsigned long long* waited = nullptr, int64_t row = 0, int64_t nrows = 0) {
   using R = Ring<NB>;
+  if constexpr (BF) {
+    u32x4 bb[NB / 2];
+    round_block<NB>(act, 0, bb[0]);
+    const bool st = store_base != nullptr && store_off >= 0;
+#pragma unroll
+    for (int c = 0; c < R::NCH; ++c) {
+      lds_barrier();
+      const float4* cur = lds + slot * R::CH4;
+      if (++slot == R::NR) slot = 0;
+      if (c == 0 && from_header) {
+        const float* bl_ = reinterpret_cast<const float*>(cur);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const float4 x = *reinterpret_cast<const float4*>(bl_ + 16 * t + 4 * (lane >> 4));
+          acc[t] = f32x4{x.x, x.y, x.z, x.w};
+        }
+      }
+      if (st) {   // two 16-feature blocks of the saved activation per chunk, spread over the stage like the fp32 pairs
+        store_block_bf16<NB>(act, store_base, store_off / (NB * 16), lane >> 4, 2 * c);
+        store_block_bf16<NB>(act, store_base, store_off / (NB * 16), lane >> 4, 2 * c + 1);
+      }
+      const float4* body = cur + kChunkHdrFloats / 4 + lane;
+#pragma unroll
+      for (int t = 0; t < NB; t += 2) {
+        const float4 h0 = body[(t * 3 + 0) * 64], h1 = body[(t * 3 + 3) * 64];
+        acc[t] = mma(h0, bb[c], acc[t]);
+        acc[t + 1] = mma(h1, bb[c], acc[t + 1]);
+        if (t == 0) {
+          if (c + 1 < R::NCH) round_block<NB>(act, c + 1, bb[c + 1]);
+          else if (mask_rows) store_mask_bits<NB, true>(act, store_base, mask_rows, store_off, lane >> 4);
+        }
+      }
+    }
+    return;
+  }
   // The per-element VALU work of a stage (three-way split, sign bits) is spread over the chunks instead of sitting
   // in front of the first MFMA: only K block 0 is split up front, block c + 1 is split in the shadow of chunk c's
   // MFMAs (an MFMA occupies the issue port for 4 of its 16 cycles).
@@ -381,7 +463,7 @@ __device__ __forceinline__ float dot_features(const f32x4 (&v)[NB], const float*
 // -------------------------------------------------------------------------------- forward chain
 // TIMING (experiments, profiles/tile_timeline.py): phase stamps of wave 0; a separate instantiation so that the
 // production kernel carries none of it.
-template <int NB, int IN, int OUT, bool TIMING = false>
+template <int NB, int IN, int OUT, bool TIMING = false, bool BF = false>
 __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -485,8 +567,8 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     continue;
   }
   for (int l = 0; l < a.nstage; ++l) {
-    mfma_stage<NB, TIMING>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode & 3, (a.store_mode & 4) ? 0 : a.R, &waited,
-                           row, (a.store_mode & 8) ? 0 : a.R);  // acc = bias + W act
+    mfma_stage<NB, TIMING, BF>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode & 3, (a.store_mode & 4) ? 0 : a.R, &waited,
+                               row, (a.store_mode & 8) ? 0 : a.R);  // acc = bias + W act
     stamp();          // stage l done
     pending = nullptr;
     if (IN == IN_ROWS2 && l == 0) {
@@ -524,6 +606,11 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     for (int t = 0; t < NB; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] *= rstd;
+    if constexpr (BF) {   // edge messages of the bf16 precision: stored (and consumed by the aggregation) as bf16
+      store_rows_bf16<NB>(acc, a.y, roff, lg);
+      if (a.rstd && lg == 0) a.rstd[row] = rstd;
+      continue;
+    }
     store_rows<NB, false>(acc, a.yln, roff, lg);
     if (a.rstd && lg == 0) a.rstd[row] = rstd;
     if (a.resid) {
@@ -566,7 +653,7 @@ __device__ __forceinline__ void mask_by(f32x4 (&gr)[NB], const float* act_row, i
   }
 }
 
-template <int NB, int GIN, int FIRST>
+template <int NB, int GIN, int FIRST, bool BF = false>
 __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -596,7 +683,8 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
       dyrow = a.dy + rowc * D;
     }
     load_rows<NB>(g, dyrow, lg);
-    load_rows<NB>(acc, a.yln + rowc * D, lg);  // acc = normalised output y
+    if constexpr (BF) load_rows_bf16<NB>(acc, a.yln, rowc, lg);   // the bf16 messages the forward handed to the aggregation
+    else load_rows<NB>(acc, a.yln + rowc * D, lg);  // acc = normalised output y
     const float rs = a.rstd[rowc];
     __builtin_amdgcn_sched_barrier(0);         // all 17 loads in flight before the first use (see k_chain_fwd)
     // LayerNorm backward (no affine): dz = rstd * (dy - mean(dy) - y * mean(dy * y))
@@ -622,10 +710,10 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     unsigned mbits[mask_words<NB>()];
 #pragma unroll
     for (int w = 0; w < mask_words<NB>(); ++w)
-      mbits[w] = a.mask[k] ? reinterpret_cast<const unsigned*>(a.mask[k] + a.R * D)[rowc * (4 * mask_words<NB>()) + lg * mask_words<NB>() + w]
+      mbits[w] = a.mask[k] ? reinterpret_cast<const unsigned*>(a.mask[k] + (BF ? a.R * D / 2 : a.R * D))[rowc * (4 * mask_words<NB>()) + lg * mask_words<NB>() + w]
                            : 0xffffffffu;
     zero_tile<NB>(acc);
-    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode & 3, 0, nullptr, row, (a.store_mode & 8) ? 0 : a.R);
+    mfma_stage<NB, false, BF>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode & 3, 0, nullptr, row, (a.store_mode & 8) ? 0 : a.R);
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
@@ -653,7 +741,8 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
       store_rows<NB, false>(acc, a.dx, roff, lg);
     }
   }
-  store_rows<NB, false>(g, pending, roff, lg);
+  if constexpr (BF) store_rows_bf16<NB>(g, pending, roff, lg);
+  else store_rows<NB, false>(g, pending, roff, lg);
   }  // tile loop
 }
 
@@ -698,6 +787,16 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
       launched = true;
     }
   }
+  if constexpr ((NB == 8 || NB == 16) && IN == IN_EDGE && OUT == OUT_LN) {   // the bf16 precision exists for the edge MLP only
+    if (a.bf16 && !launched) {
+      static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+      BSMS_REQUIRE(battr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (bf16 build)");
+      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, true>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+      launched = true;
+    }
+  }
+  BSMS_REQUIRE(launched || !a.bf16, BSMS_E_UNSUPPORTED, "chain_fwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
   if (!launched)
     hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
@@ -732,6 +831,17 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", lds);
   a.ntiles = (int)ceil_div(a.R, kTileRows);
+  if constexpr ((NB == 8 || NB == 16) && GIN == G_EDGE_LN && FIRST == F_NONE) {
+    if (a.bf16) {
+      static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+      BSMS_REQUIRE(battr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve LDS (bf16 build)");
+      hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, true>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+      BSMS_LAUNCH_CHECK();
+      return BSMS_OK;
+    }
+  }
+  BSMS_REQUIRE(!a.bf16, BSMS_E_UNSUPPORTED, "chain_bwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
   hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;

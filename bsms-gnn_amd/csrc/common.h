@@ -67,15 +67,16 @@ int edge_conv_add(const bsms_plan* p, const float* x, int64_t B, int64_t D, cons
 // earlier in the same step; `resid2` (nullable): the skip connection added to the block's output (ops/BSMS.py:102).
 size_t gmp_pack_bytes(int64_t D, int hidden);
 int gmp_prepack(int64_t B, int64_t N, int64_t E, int64_t D, int64_t p, int hidden, const float* const* params,
-                void* saved, void* work, void* packs_base, hipStream_t stream);
+                void* saved, void* work, void* packs_base, hipStream_t stream, int precision = BSMS_F32);
+size_t gmp_saved_bytes_p(int64_t B, int64_t N, int64_t E, int64_t D, int hidden, int precision);
 int gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
                  int64_t pos_bstride, int hidden, const float* const* params, float* out, void* saved, void* work,
-                 void* packs_base, bool do_prepack, const float* resid2, hipStream_t stream);
+                 void* packs_base, bool do_prepack, const float* resid2, hipStream_t stream, int precision = BSMS_F32);
 // `defer_slot` < 0: the side lanes are joined before returning (ABI semantics).  0/1: they are only MARKED in that slot;
 // the caller joins later with side_wait_mark on both lanes and must not touch `work` or read `grads` before that.
 int gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, const float* grad_out, int64_t B, int64_t D,
                  int64_t p, int64_t pos_bstride, int hidden, const float* const* params, const void* saved, void* work,
-                 float* grad_x, float* const* grads, int defer_slot, hipStream_t stream);
+                 float* grad_x, float* const* grads, int defer_slot, hipStream_t stream, int precision = BSMS_F32);
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 }  // namespace bsms

@@ -69,14 +69,16 @@ struct GmpSaved {
 // only the messages, the aggregate and the forward packs, carved from the scratch buffer instead.
 // `packs_base` (inference only, nullable): carve the weight packs from there instead of behind the messages, so that
 // they can be filled ahead of the call and survive the scratch reuse of other blocks.
+// `bf`: bf16 precision -- the edge activations and the messages are bf16 (half the floats; the sign bits keep their size)
 GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H, bool training = true,
-                         void* packs_base = nullptr) {
+                         void* packs_base = nullptr, bool bf = false) {
   Carver c(base);
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
+  const size_t edge_act = bf ? re * size_t(D) / 2 + re * mask_words_per_row(D) : act_floats(re, D);
   if (training)
-    for (int l = 0; l < H; ++l) s.e_act[l] = c.take(act_floats(re, D));
-  s.e_y = c.take(re * D);
+    for (int l = 0; l < H; ++l) s.e_act[l] = c.take(edge_act);
+  s.e_y = c.take(bf ? re * D / 2 : re * D);
   if (training) s.e_rstd = c.take(re);
   if (training) s.e_fiber = c.take(re * 8);   // [B*E, fiber_ld(p)]: sized for the widest pitch (p is not part of the size query)
   s.aggr = c.take(rn * D);
@@ -151,12 +153,14 @@ extern "C" size_t bsms_gmp_work_bytes(int64_t B, int64_t N, int64_t E, int64_t D
 
 namespace {
 // where the saved tensors / packs of a forward call live (see carve_gmp_saved)
-GmpSaved locate_saved(void* saved, const GmpWork& wk, int64_t B, int64_t N, int64_t E, int64_t D, int H, void* packs_base) {
-  return saved ? carve_gmp_saved(saved, B, N, E, D, H, true)
-               : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false, packs_base);  // inference: lives in the gradient scratch
+GmpSaved locate_saved(void* saved, const GmpWork& wk, int64_t B, int64_t N, int64_t E, int64_t D, int H, void* packs_base,
+                      bool bf = false) {
+  return saved ? carve_gmp_saved(saved, B, N, E, D, H, true, nullptr, bf)
+               : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false, packs_base, bf);  // inference: lives in the gradient scratch
 }
 
-int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training, const float* const* params, hipStream_t s) {
+int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training, const float* const* params, hipStream_t s,
+                  bool bf = false) {
   const int nl = H + 1;
   const float* const* pn = params;            // mlp_node: W_l = pn[2l], b_l = pn[2l+1]
   const float* const* pe = params + 2 * nl;   // mlp_edge
@@ -169,9 +173,10 @@ int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training
     add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG_T, sv.e_wit);
     add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG_T, sv.e_wjt);
   }
-  for (int l = 1; l <= H; ++l) {
+  for (int l = 1; l <= H; ++l) {   // the D x D Linears of the edge MLP: bf16 operands in the bf16 precision
     add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.e_w[l], pe[2 * l + 1]);
-    if (training) add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]);
+    t.d[t.n - 1].bf16 = bf;
+    if (training) { add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]); t.d[t.n - 1].bf16 = bf; }
   }
   add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x, pn[1]);
   add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG, sv.n_w0a);
@@ -192,30 +197,36 @@ size_t bsms::gmp_pack_bytes(int64_t D, int hidden) {   // inference packs of one
 }
 
 int bsms::gmp_prepack(int64_t B, int64_t N, int64_t E, int64_t D, int64_t p, int H, const float* const* params, void* saved,
-                      void* work, void* packs_base, hipStream_t s) {
+                      void* work, void* packs_base, hipStream_t s, int precision) {
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
-  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base);
-  return prepack_block(sv, D, p, H, saved != nullptr, params, s);
+  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, precision == BSMS_BF16);
+  return prepack_block(sv, D, p, H, saved != nullptr, params, s, precision == BSMS_BF16);
+}
+size_t bsms::gmp_saved_bytes_p(int64_t B, int64_t N, int64_t E, int64_t D, int hidden, int precision) {
+  if (hidden < 1 || hidden >= kMaxStages) return 0;
+  return carve_gmp_saved(nullptr, B, N, E, D, hidden, true, nullptr, precision == BSMS_BF16).bytes;
 }
 
 extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
                             int64_t pos_bstride, int H, const float* const* params, float* out, void* saved,
                             void* work, bsms_stream_t stream) {
   return bsms::gmp_fwd_core(plan, x, pos, B, D, p, pos_bstride, H, params, out, saved, work, nullptr, true, nullptr,
-                            as_stream(stream));
+                            as_stream(stream), BSMS_F32);
 }
 
 int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
                        int64_t pos_bstride, int H, const float* const* params, float* out, void* saved, void* work,
-                       void* packs_base, bool do_prepack, const float* resid2, hipStream_t s) {
+                       void* packs_base, bool do_prepack, const float* resid2, hipStream_t s, int precision) {
   int rc = check_gmp(plan, B, D, p, H, "gmp_fwd");
   if (rc) return rc;
   BSMS_REQUIRE(x && pos && params && out && work, BSMS_E_INVALID_ARG, "gmp_fwd: null argument");
+  const bool bf = precision == BSMS_BF16;
+  BSMS_REQUIRE(!bf || ((D == 128 || D == 256) && p <= 3), BSMS_E_UNSUPPORTED, "gmp_fwd: bf16 precision needs D = 128 / 256 and pos_dim <= 3");
   const int64_t N = plan->N, E = plan->E;
   const bool training = saved != nullptr;     // saved == NULL: inference, nothing is kept for a backward
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
-  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base);
-  if (do_prepack && (rc = prepack_block(sv, D, p, H, training, params, s))) return rc;
+  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, bf);
+  if (do_prepack && (rc = prepack_block(sv, D, p, H, training, params, s, bf))) return rc;
 
   // node pre-projections
   {
@@ -232,6 +243,7 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.src = plan->src; a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
     a.Ps = wk.Ps; a.Pd = wk.Pd; a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p;
     a.fiber_out = training ? sv.e_fiber : nullptr;
+    a.bf16 = bf;
     a.nstage = H;
     for (int st = 0; st < H; ++st) {
       a.wp[st] = reinterpret_cast<const float4*>(sv.e_w[st + 1]);
@@ -248,7 +260,7 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     if ((rc = launch_chain_fwd((int)D, IN_EDGE, OUT_LN, a, s))) return rc;
   }
   // aggregation (scatter_sum over targets, ops/basic.py:94)
-  if ((rc = rowsum_plan_order(plan, sv.e_y, B, D, sv.aggr, s))) return rc;
+  if ((rc = bf ? rowsum_plan_order_bf16(plan, sv.e_y, B, D, sv.aggr, s) : rowsum_plan_order(plan, sv.e_y, B, D, sv.aggr, s))) return rc;
   // node MLP + LayerNorm + residual
   {
     ChainFwdArgs a{};
@@ -271,7 +283,7 @@ extern "C" int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float
                             int64_t D, int64_t p, int64_t pos_bstride, int H, const float* const* params,
                             const void* saved, void* work, float* grad_x, float* const* grads, bsms_stream_t stream) {
   return bsms::gmp_bwd_core(plan, x, pos, grad_out, B, D, p, pos_bstride, H, params, saved, work, grad_x, grads, -1,
-                            as_stream(stream));
+                            as_stream(stream), BSMS_F32);
 }
 
 namespace {
@@ -294,9 +306,11 @@ struct LaneScope {
 
 int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, const float* grad_out, int64_t B, int64_t D,
                        int64_t p, int64_t pos_bstride, int H, const float* const* params, const void* saved, void* work,
-                       float* grad_x, float* const* grads, int defer_slot, hipStream_t s) {
+                       float* grad_x, float* const* grads, int defer_slot, hipStream_t s, int precision) {
   int rc = check_gmp(plan, B, D, p, H, "gmp_bwd");
   if (rc) return rc;
+  const bool bf = precision == BSMS_BF16;
+  BSMS_REQUIRE(!bf || ((D == 128 || D == 256) && p <= 3), BSMS_E_UNSUPPORTED, "gmp_bwd: bf16 precision needs D = 128 / 256 and pos_dim <= 3");
   BSMS_REQUIRE(x && pos && grad_out && params && saved && work && grad_x && grads, BSMS_E_INVALID_ARG,
                "gmp_bwd: null argument");
   const int64_t N = plan->N, E = plan->E;
@@ -304,7 +318,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   float* const* gn = grads;
   float* const* ge = grads + 2 * nl;
   const int ldE0 = int(2 * D + p + 1);
-  GmpSaved sv = carve_gmp_saved(const_cast<void*>(saved), B, N, E, D, H);
+  GmpSaved sv = carve_gmp_saved(const_cast<void*>(saved), B, N, E, D, H, true, nullptr, bf);
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
 
   // node MLP backward: grad_x = grad_out (residual) + g0 W0x ; daggr = g0 W0a
@@ -328,6 +342,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     ChainBwdArgs a{};
     a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd; a.store_mode = ((g_debug_flags & 2) ? 0 : (g_debug_flags & 256) ? 2 : 1) | ((g_debug_flags & 128) ? 8 : 0);
     a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
+    a.bf16 = bf;
     a.nstage = H;
     a.gstore[0] = wk.gE[H];
     for (int k = 0; k < H; ++k) {
@@ -358,9 +373,12 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     int nj = 0;
     auto add_job = [&](const float* G, const float* A, float* dW, float* db, int64_t R, int ldw, int col0) {
       WgradJob& j = jobs[nj++];
-      j.G = G; j.A = A; j.dW = dW; j.db = db; j.R = R; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldw; j.col0 = col0;
+      j.G = G; j.A = A; j.dW = dW; j.db = db; j.R = R; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldw; j.col0 = col0; j.bf16 = 0;
     };
-    for (int l = 1; l <= H; ++l) add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0);
+    for (int l = 1; l <= H; ++l) {   // edge Linears: bf16 gradient and activation tensors in the bf16 precision
+      add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0);
+      jobs[nj - 1].bf16 = bf;
+    }
     for (int l = 1; l <= H; ++l) add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0);
     add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0);
     add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D);
@@ -386,7 +404,8 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   sw.R = B * E; sw.D = (int)D;
   int nwg = 0;
   if ((rc = rowsum_source_target_fiber(plan, wk.gE[0], B, D, wk.dPs, wk.dPd, sv.e_fiber, fiber_ld(p), int(p + 1),
-                                       reinterpret_cast<float*>(wk.sw), small_wgrad_part_blocks(wk.sw_bytes, (int)D), &nwg, s))) return rc;
+                                       reinterpret_cast<float*>(wk.sw), small_wgrad_part_blocks(wk.sw_bytes, (int)D), &nwg, s, bf))) return rc;
+  BSMS_REQUIRE(nwg > 0 || !bf, BSMS_E_UNSUPPORTED, "gmp_bwd: bf16 precision needs the fused scatter kernel (D = 128 / 256, pos_dim <= 3)");
   if (nwg == 0) {   // shape not built into the fused kernel (D < 128, pos_dim > 3): separate passes
     if ((rc = rowsum_source_and_target(plan, wk.gE[0], B, D, wk.dPs, wk.dPd, s))) return rc;
     if ((rc = launch_small_wgrad(sw, wk.sw, s2))) return rc;
@@ -397,7 +416,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   {
     WgradJob jobs[2];
     auto set = [&](WgradJob& j, const float* G, int col0) {
-      j.G = G; j.A = x; j.dW = ge[0]; j.db = nullptr; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldE0; j.col0 = col0;
+      j.G = G; j.A = x; j.dW = ge[0]; j.db = nullptr; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldE0; j.col0 = col0; j.bf16 = 0;
     };
     set(jobs[0], wk.dPs, int(p + 1));
     set(jobs[1], wk.dPd, int(p + 1 + D));

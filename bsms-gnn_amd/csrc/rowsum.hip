@@ -32,6 +32,17 @@ struct RowSumArgs {
   int32_t n_out, B, D;
 };
 
+// four consecutive features of a row tensor at ELEMENT offset e: fp32 storage, or (XBF) bf16 storage widened exactly
+template <bool XBF>
+__device__ __forceinline__ float4 ld4(const float* base, int64_t e) {
+  if (XBF) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + e);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(base + e);
+}
+
 template <bool WEIGHTED>
 __device__ __forceinline__ float4 accum(float4 acc, float4 v, float w) {
   if (WEIGHTED) {  // product rounded, then added: same two roundings as x[i]*ew followed by scatter_add_
@@ -49,8 +60,8 @@ __device__ __forceinline__ float4 accum(float4 acc, float4 v, float w) {
 // batch -- an s_waitcnt vmcnt(0) before every row load -- and the coarse levels, which have too few waves to hide
 // that, run at a fifth of the bandwidth.)  A skipped slot (MAPPED, negative map entry) reads row 0 and is dropped
 // by a select, so the accumulator sees exactly the sequence of additions scatter_add_ performs.
-template <int U, bool WEIGHTED, bool MAPPED, bool HAS_XIDX, bool HAS_WIDX>
-__device__ __forceinline__ float4 rowsum_batch(const RowSumArgs& a, const float* xcol, int q, float4 acc) {
+template <int U, bool WEIGHTED, bool MAPPED, bool HAS_XIDX, bool HAS_WIDX, bool XBF = false>
+__device__ __forceinline__ float4 rowsum_batch(const RowSumArgs& a, int64_t xcol, int q, float4 acc) {   // xcol: element offset of this lane's columns in batch item b
   int xr[U];
   float w4[U];
   float4 v4[U];
@@ -63,7 +74,7 @@ __device__ __forceinline__ float4 rowsum_batch(const RowSumArgs& a, const float*
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int safe = (MAPPED && xr[u] < 0) ? 0 : xr[u];
-    v4[u] = *reinterpret_cast<const float4*>(xcol + int64_t(safe) * a.D);
+    v4[u] = ld4<XBF>(a.x, xcol + int64_t(safe) * a.D);
     w4[u] = WEIGHTED ? a.w[HAS_WIDX ? a.widx[q + u] : q + u] : 1.f;
   }
   __builtin_amdgcn_sched_barrier(0);   // all U row loads are in flight before the first add (hipcc would interleave)
@@ -78,7 +89,7 @@ __device__ __forceinline__ float4 rowsum_batch(const RowSumArgs& a, const float*
 // LPR lanes cooperate on one output row; each lane owns float4 column groups c4, c4+LPR, ...
 // DEEP: coarse levels (few rows, up to ~170 edges each): the critical path is (edges / batch) dependent HBM round
 // trips of the longest row, so batch 32 rows (128 registers; occupancy is irrelevant there).
-template <int LPR, bool WEIGHTED, bool MAPPED, bool DEEP, bool HAS_XIDX, bool HAS_WIDX>
+template <int LPR, bool WEIGHTED, bool MAPPED, bool DEEP, bool HAS_XIDX, bool HAS_WIDX, bool XBF = false>
 __device__ __forceinline__ void rowsum_body(const RowSumArgs& a) {
   const int64_t worker = (int64_t(blockIdx.x) * 256 + threadIdx.x) / LPR;
   const int lane = threadIdx.x % LPR;
@@ -86,18 +97,17 @@ __device__ __forceinline__ void rowsum_body(const RowSumArgs& a) {
   const int b = int(worker / a.n_out), r = int(worker % a.n_out);
   const int v = a.rows ? a.rows[r] : r;
   const int q0 = a.rowptr[v], q1 = a.rowptr[v + 1];
-  const float* xb = a.x + b * a.x_bstride;
   float* ob = a.out + b * a.out_bstride + int64_t(r) * a.D;
   const int d4 = a.D >> 2;
   for (int c4 = lane; c4 < d4; c4 += LPR) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* xcol = xb + c4 * 4;
+    const int64_t xcol = b * a.x_bstride + c4 * 4;
     int q = q0;
     if (DEEP)
-      for (; q + 32 <= q1; q += 32) acc = rowsum_batch<32, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
-    for (; q + 8 <= q1; q += 8) acc = rowsum_batch<8, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
-    for (; q + 2 <= q1; q += 2) acc = rowsum_batch<2, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
-    for (; q < q1; ++q) acc = rowsum_batch<1, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX>(a, xcol, q, acc);
+      for (; q + 32 <= q1; q += 32) acc = rowsum_batch<32, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc);
+    for (; q + 8 <= q1; q += 8) acc = rowsum_batch<8, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc);
+    for (; q + 2 <= q1; q += 2) acc = rowsum_batch<2, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc);
+    for (; q < q1; ++q) acc = rowsum_batch<1, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc);
     if (a.addend) {   // (row sum) + addend: one more rounded add, exactly what a separate elementwise add would do
       const float4 ad = *reinterpret_cast<const float4*>(a.addend + b * a.out_bstride + int64_t(r) * a.D + c4 * 4);
       acc.x += ad.x; acc.y += ad.y; acc.z += ad.z; acc.w += ad.w;
@@ -119,6 +129,12 @@ __global__ __launch_bounds__(256) void k_rowsum_v4(RowSumArgs a) {
   }
 }
 
+// the edge aggregation of the bf16 precision: messages stored as bf16, sums and output fp32
+template <int LPR, bool DEEP>
+__global__ __launch_bounds__(256) void k_rowsum_bf16in(RowSumArgs a) {
+  rowsum_body<LPR, false, false, DEEP, false, false, true>(a);
+}
+
 // two unweighted, unmapped sums of the SAME shape in one launch (blockIdx.y picks the job): the scatters of the first
 // edge gradient to its source and to its target rows
 template <int LPR, bool DEEP>
@@ -135,13 +151,13 @@ __global__ __launch_bounds__(256) void k_rowsum_pair(RowSumArgs a0, RowSumArgs a
 // the plain row sum) of its bias.  The 256 / LPR workers of a workgroup are combined in fixed order through LDS and
 // written as one partial block; k_small_reduce (wgrad.hip) sums the blocks in fixed order.  This replaces a separate
 // pass over the whole [B,E,D] gradient (k_small_wgrad read it a third time: 128 MB at airfoil L0).
-template <int U, int NS>
-__device__ __forceinline__ void fiber_batch(const float* xcol, const float* frow, int D, int ld, int q, float4& acc,
+template <int U, int NS, bool XBF = false>
+__device__ __forceinline__ void fiber_batch(const float* xbase, int64_t xcol, const float* frow, int D, int ld, int q, float4& acc,
                                             float4 (&accf)[NS]) {
   float4 v[U], f0[U], f1[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    v[u] = *reinterpret_cast<const float4*>(xcol + int64_t(q + u) * D);
+    v[u] = ld4<XBF>(xbase, xcol + int64_t(q + u) * D);
     f0[u] = *reinterpret_cast<const float4*>(frow + int64_t(q + u) * ld);
     if (NS > 4) f1[u] = *reinterpret_cast<const float4*>(frow + int64_t(q + u) * ld + 4);
   }
@@ -161,14 +177,14 @@ __device__ __forceinline__ void fiber_batch(const float* xcol, const float* frow
 
 constexpr int kSmallRows = 10;   // partial block = kSmallRows x D floats: rows 0..7 narrow products, 8 colsum(G), 9 colsum(S) (wgrad.hip)
 
-template <int LPR, int NS, bool DEEP>
+template <int LPR, int NS, bool DEEP, bool XBF = false>
 __global__ __launch_bounds__(256) void k_rowsum_pair_fiber(RowSumArgs a0, RowSumArgs a1, const float* fiber, int ld, float* part,
                                                           int nsrc_blocks) {
   // blocks [0, nsrc_blocks): by source, one worker per output row (as k_rowsum_pair); the remaining gridDim.x -
   // nsrc_blocks blocks: by target, workers stride over the rows so that the number of partial blocks stays small
   if (int(blockIdx.x) < nsrc_blocks) {
-    if (a0.xidx) rowsum_body<LPR, false, false, DEEP, true, false>(a0);
-    else rowsum_body<LPR, false, false, DEEP, false, false>(a0);
+    if (a0.xidx) rowsum_body<LPR, false, false, DEEP, true, false, XBF>(a0);
+    else rowsum_body<LPR, false, false, DEEP, false, false, XBF>(a0);
     return;
   }
   __shared__ float4 red[256];
@@ -184,14 +200,14 @@ __global__ __launch_bounds__(256) void k_rowsum_pair_fiber(RowSumArgs a0, RowSum
     // D == 4 * LPR: one float4 column group per lane
     const int b = int(worker / a.n_out), r = int(worker % a.n_out);
     const int q0 = a.rowptr[r], q1 = a.rowptr[r + 1];
-    const float* xcol = a.x + b * a.x_bstride + lane * 4;
+    const int64_t xcol = b * a.x_bstride + lane * 4;
     const float* frow = fiber + int64_t(b) * (a.x_bstride / a.D) * ld;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int q = q0;
     if (DEEP)
-      for (; q + 16 <= q1; q += 16) fiber_batch<16, NS>(xcol, frow, a.D, ld, q, acc, accf);
-    for (; q + 4 <= q1; q += 4) fiber_batch<4, NS>(xcol, frow, a.D, ld, q, acc, accf);
-    for (; q < q1; ++q) fiber_batch<1, NS>(xcol, frow, a.D, ld, q, acc, accf);
+      for (; q + 16 <= q1; q += 16) fiber_batch<16, NS, XBF>(a.x, xcol, frow, a.D, ld, q, acc, accf);
+    for (; q + 4 <= q1; q += 4) fiber_batch<4, NS, XBF>(a.x, xcol, frow, a.D, ld, q, acc, accf);
+    for (; q < q1; ++q) fiber_batch<1, NS, XBF>(a.x, xcol, frow, a.D, ld, q, acc, accf);
     *reinterpret_cast<float4*>(a.out + b * a.out_bstride + int64_t(r) * a.D + lane * 4) = acc;
     accs.x += acc.x; accs.y += acc.y; accs.z += acc.z; accs.w += acc.w;
   }
@@ -372,6 +388,29 @@ int rowsum_plan_order(const bsms_plan* p, const float* x, int64_t B, int64_t D, 
   a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
   return launch_rowsum(a, s);
 }
+// the same with bf16 messages (bf16 precision of the GMP block): D = 128 / 256 only
+int rowsum_plan_order_bf16(const bsms_plan* p, const float* x_bf16, int64_t B, int64_t D, float* out, hipStream_t s) {
+  BSMS_REQUIRE(D == 128 || D == 256, BSMS_E_UNSUPPORTED, "bf16 aggregation: D=%lld (128, 256)", (long long)D);
+  RowSumArgs a{};
+  a.rowptr = p->rowptr;
+  a.x = x_bf16; a.out = out;
+  a.x_bstride = p->E * D; a.out_bstride = p->N * D;
+  a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
+  const int64_t workers = B * p->N;
+  if (workers == 0) return BSMS_OK;
+  const int lpr = int(D / 4);
+  const dim3 grid((unsigned)ceil_div(workers * lpr, 256));
+  const bool deep = workers * lpr < kDeepBelowThreads;
+  if (D == 128) {
+    if (deep) hipLaunchKernelGGL((k_rowsum_bf16in<32, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_rowsum_bf16in<32, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (deep) hipLaunchKernelGGL((k_rowsum_bf16in<64, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_rowsum_bf16in<64, false>), grid, dim3(256), 0, s, a);
+  }
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
 // out[b, i, :] = sum over edges whose SOURCE is i of x[b, slot(e), :]   (x in plan order)
 int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s) {
   RowSumArgs a{};
@@ -384,7 +423,8 @@ int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, f
 // by source and by target at once + the narrow weight-gradient partials (see k_rowsum_pair_fiber); returns the number
 // of partial blocks in *nwg, or 0 there if this shape is not built (the caller then runs the separate kernels)
 int rowsum_source_target_fiber(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* outS, float* outD,
-                               const float* fiber, int ld, int ncols, float* part, int64_t part_blocks, int* nwg, hipStream_t s) {
+                               const float* fiber, int ld, int ncols, float* part, int64_t part_blocks, int* nwg, hipStream_t s,
+                               bool x_bf16) {
   *nwg = 0;
   const int64_t workers = B * p->N;
   const int lpr = int(D / 4);
@@ -400,10 +440,13 @@ int rowsum_source_target_fiber(const bsms_plan* p, const float* x, int64_t B, in
   const dim3 grid((unsigned)(blocks + tgt_blocks));
   const bool deep = workers * lpr < kDeepBelowThreads;
   const int nsrc = (int)blocks;
-#define BSMS_PF(L, NS)                                                                                                          \
-  do {                                                                                                                          \
-    if (deep) hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, true>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part, nsrc);     \
-    else hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, false>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part, nsrc);         \
+#define BSMS_PF(L, NS)                                                                                                                 \
+  do {                                                                                                                                 \
+    if (x_bf16) {                                                                                                                      \
+      if (deep) hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, true, true>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part, nsrc);    \
+      else hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, false, true>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part, nsrc);        \
+    } else if (deep) hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, true>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part, nsrc);     \
+    else hipLaunchKernelGGL((k_rowsum_pair_fiber<L, NS, false>), grid, dim3(256), 0, s, a0, a1, fiber, ld, part, nsrc);                \
   } while (0)
   if (D == 128) {
     if (ncols == 1) BSMS_PF(32, 1); else if (ncols == 2) BSMS_PF(32, 2); else if (ncols == 3) BSMS_PF(32, 3); else BSMS_PF(32, 4);
@@ -448,6 +491,13 @@ extern "C" int bsms_segment_sum_fwd(const bsms_plan_t* p, const float* src, int6
   a.x_bstride = p->E * D; a.out_bstride = p->N * D;
   a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
   return launch_rowsum(a, as_stream(stream));
+}
+
+extern "C" int bsms_segment_sum_bf16(const bsms_plan_t* p, const void* src_bf16, int64_t B, int64_t D, float* out,
+                                     bsms_stream_t stream) {
+  BSMS_REQUIRE(p && out && (src_bf16 || p->E == 0), BSMS_E_INVALID_ARG, "segment_sum_bf16: null argument");
+  BSMS_REQUIRE(B >= 0, BSMS_E_SHAPE, "segment_sum_bf16: bad B=%lld", (long long)B);
+  return bsms::rowsum_plan_order_bf16(p, reinterpret_cast<const float*>(src_bf16), B, D, out, as_stream(stream));
 }
 
 extern "C" int bsms_segment_sum_bwd(const bsms_plan_t* p, const float* grad_out, int64_t B, int64_t D,

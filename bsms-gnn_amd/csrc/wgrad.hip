@@ -91,7 +91,9 @@ constexpr int NPF = 3;            // chunks in flight in registers beyond the on
 static_assert(NPF == 3, "the step schedule in k_wgrad is written out for three register sets");
 
 // TIMING: experiments (profiles/wgrad_timeline.py); the production instantiation carries no stamps
-template <bool TIMING>
+// JB: every job of the launch is a bf16 job (WgradJob::bf16); a compile-time switch so that the fp32 instantiation
+// keeps its branch-free load schedule
+template <bool TIMING, bool JB = false>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   extern __shared__ __attribute__((aligned(16))) short planes[];  // [2 buffers][G|A][hi|mid|lo][32 rows][LROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,8 +114,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   const bool vg = n0 + scol < D, va = k0 + scol < D;
   // loads are unconditional (a predicated load costs a branch and a vmcnt(0)): out-of-range rows / columns read a
   // valid address and are zeroed when they are staged
+  // bf16 job (bf16 precision of a GMP block: edge gradients and edge activations are stored as bf16): both matrices are
+  // read as 4 x bf16 = 8 bytes per thread, staged into the `hi` plane as they are and multiplied with ONE product
+  constexpr bool jb = JB;
   const float* gsrc = job.G + (vg ? n0 + scol : 0);
   const float* asrc = job.A + (va ? k0 + scol : 0);
+  const unsigned short* gsrc16 = reinterpret_cast<const unsigned short*>(job.G) + (vg ? n0 + scol : 0);
+  const unsigned short* asrc16 = reinterpret_cast<const unsigned short*>(job.A) + (va ? k0 + scol : 0);
   const int64_t rlast = r1 - 1;
   f32x4 sg[NPF], sa[NPF];
   bool live[NPF];
@@ -121,8 +128,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
     const int64_t r = r0 + int64_t(chunk) * RC + srow;
     live[set] = r < r1;
     const int64_t rc = r < r1 ? r : rlast;
-    sg[set] = *reinterpret_cast<const f32x4*>(gsrc + rc * job.ldg);
-    sa[set] = *reinterpret_cast<const f32x4*>(asrc + rc * job.lda);
+    if (jb) {
+      const u32x2 g2 = *reinterpret_cast<const u32x2*>(gsrc16 + rc * job.ldg), a2 = *reinterpret_cast<const u32x2*>(asrc16 + rc * job.lda);
+      sg[set] = f32x4{__uint_as_float(g2[0]), __uint_as_float(g2[1]), 0.f, 0.f};
+      sa[set] = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[1]), 0.f, 0.f};
+    } else {
+      sg[set] = *reinterpret_cast<const f32x4*>(gsrc + rc * job.ldg);
+      sa[set] = *reinterpret_cast<const f32x4*>(asrc + rc * job.lda);
+    }
   };
   const bool want_db = job.db && bj == 0;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};  // column sums of G over this thread's rows
@@ -131,6 +144,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
     u32x2 h, m, l;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const f32x4 gq = (live[set] && vg) ? sg[set] : zero, aq = (live[set] && va) ? sa[set] : zero;
+    if (jb) {   // the raw bf16 quads go to the hi planes; mid / lo are not read for this job
+      const unsigned g0 = __float_as_uint(gq[0]), g1 = __float_as_uint(gq[1]);
+      *reinterpret_cast<u32x2*>(dst + 0 * PLANE) = u32x2{g0, g1};
+      *reinterpret_cast<u32x2*>(dst + 3 * PLANE) = u32x2{__float_as_uint(aq[0]), __float_as_uint(aq[1])};
+      if (want_db)
+        csum += f32x4{__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u), __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
+      return;
+    }
     split_quad(gq, h, m, l);
     *reinterpret_cast<u32x2*>(dst + 0 * PLANE) = h;
     *reinterpret_cast<u32x2*>(dst + 1 * PLANE) = m;
@@ -175,6 +196,18 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   auto multiply = [&](auto buf_tag) {
     constexpr int BUF = decltype(buf_tag)::value;
     const short* buf = planes + BUF * (6 * PLANE);
+    if (jb) {
+      bf16x8 g1[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) g1[a] = column_fragment(buf + 0 * PLANE, 32 * wr + 16 * a, lane);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bf16x8 a1 = column_fragment(buf + 3 * PLANE, 32 * wc + 16 * b, lane);
+        acc[0][b] = mma(g1[0], a1, acc[0][b]);
+        acc[1][b] = mma(g1[1], a1, acc[1][b]);
+      }
+      return;
+    }
     bf16x8 gh[2], gm[2], gl[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -468,7 +501,7 @@ size_t wgrad_work_bytes(int D, int njobs) {
   return size_t(kMaxTiles) * (TB * TB + TB) * sizeof(float);
 }
 
-int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t s) {
+static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t s, bool bf) {
   BSMS_REQUIRE(njobs >= 0 && njobs <= kMaxWgradJobs, BSMS_E_INVALID_ARG, "wgrad: %d jobs (max %d)", njobs, kMaxWgradJobs);
   BSMS_REQUIRE(D % 4 == 0 && D <= 256, BSMS_E_UNSUPPORTED, "wgrad: D=%d", D);
   if (njobs == 0) return BSMS_OK;
@@ -510,11 +543,33 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   BSMS_REQUIRE(attr == hipSuccess && attr_t == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS", lds);
-  if (tab.timing) hipLaunchKernelGGL(k_wgrad<true>, dim3(first), dim3(WG_THREADS), lds, s, tab);
+  if (bf) {
+    static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<false, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    BSMS_REQUIRE(attr_b == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (bf16 build)", lds);
+    hipLaunchKernelGGL((k_wgrad<false, true>), dim3(first), dim3(WG_THREADS), lds, s, tab);
+  } else if (tab.timing) hipLaunchKernelGGL(k_wgrad<true>, dim3(first), dim3(WG_THREADS), lds, s, tab);
   else hipLaunchKernelGGL(k_wgrad<false>, dim3(first), dim3(WG_THREADS), lds, s, tab);
   BSMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div((D * D + D) / 4, 64), njobs), dim3(256), 0, s, tab);
   BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
+
+// jobs of both storage types may be mixed in one call: they go out as (at most) two launches on the same stream, the
+// second reusing the partial-block workspace after the first one's reduction
+int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t s) {
+  BSMS_REQUIRE(njobs >= 0 && njobs <= kMaxWgradJobs, BSMS_E_INVALID_ARG, "wgrad: %d jobs (max %d)", njobs, kMaxWgradJobs);
+  WgradJob part[kMaxWgradJobs];
+  for (int bf = 0; bf < 2; ++bf) {
+    int n = 0;
+    for (int j = 0; j < njobs; ++j)
+      if ((jobs[j].bf16 != 0) == (bf != 0)) part[n++] = jobs[j];
+    if (n) {
+      int rc = launch_wgrad_same(D, part, n, work, s, bf != 0);
+      if (rc) return rc;
+    }
+  }
   return BSMS_OK;
 }
 

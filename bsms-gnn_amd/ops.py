@@ -462,7 +462,7 @@ class _BSGMPFunction(torch.autograd.Function):
     ~60 Python autograd nodes."""
 
     @staticmethod
-    def forward(ctx, h, pos, plans, ews, hidden, *params):
+    def forward(ctx, h, pos, plans, ews, hidden, prec, *params):
         B, _, D = h.shape
         p = pos.shape[-1]
         pos_bstride = pos.shape[-2] * p if pos.dim() == 3 else 0
@@ -471,13 +471,13 @@ class _BSGMPFunction(torch.autograd.Function):
         pl, keep_pl = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in plans])
         ewp, keep_ew = _abi.ptr_array([e.data_ptr() for e in ews])
         out = torch.empty_like(h)
-        saved = torch.empty(L.bsms_bsgmp_saved_bytes(pl, depth, B, D, p, hidden), dtype=torch.uint8, device=h.device)
+        saved = torch.empty(L.bsms_bsgmp_saved_bytes_p(pl, depth, B, D, p, hidden, prec), dtype=torch.uint8, device=h.device)
         work = _workspace(h.device, L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden))
         pp, keep = _param_ptrs(params)
-        _abi.check(L.bsms_bsgmp_fwd(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
-                                    out.data_ptr(), saved.data_ptr(), work.data_ptr(), _stream()), "bsms_bsgmp_fwd")
+        _abi.check(L.bsms_bsgmp_fwd_p(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
+                                      out.data_ptr(), saved.data_ptr(), work.data_ptr(), 0, prec, _stream()), "bsms_bsgmp_fwd")
         ctx.save_for_backward(h, pos, saved, *ews)
-        ctx.params, ctx.plans, ctx.hidden = params, plans, hidden
+        ctx.params, ctx.plans, ctx.hidden, ctx.prec = params, plans, hidden, prec
         return out
 
     @staticmethod
@@ -497,9 +497,9 @@ class _BSGMPFunction(torch.autograd.Function):
         work = _workspace(h.device, L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden))
         pp, keep = _param_ptrs(params)
         gp, keep2 = _param_ptrs(grads)
-        _abi.check(L.bsms_bsgmp_bwd(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), gout.data_ptr(), B, D, p, pos_bstride, hidden,
-                                    pp, saved.data_ptr(), work.data_ptr(), gh.data_ptr(), gp, _stream()), "bsms_bsgmp_bwd")
-        return (gh, None, None, None, None, *grads)
+        _abi.check(L.bsms_bsgmp_bwd_p(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), gout.data_ptr(), B, D, p, pos_bstride, hidden,
+                                      pp, saved.data_ptr(), work.data_ptr(), gh.data_ptr(), gp, ctx.prec, _stream()), "bsms_bsgmp_bwd")
+        return (gh, None, None, None, None, None, *grads)
 
 
 class InferenceSession:
@@ -522,7 +522,10 @@ class InferenceSession:
         return reuse
 
 
-def _bsgmp_infer(h, pos, plans, ews, hidden, params, session=None):
+PRECISIONS = {"f32": 0, "bf16": 1}   # include/bsms_hip.h: bsms_precision
+
+
+def _bsgmp_infer(h, pos, plans, ews, hidden, params, session=None, prec=0):
     B, _, D = h.shape
     p = pos.shape[-1]
     pos_bstride = pos.shape[-2] * p if pos.dim() == 3 else 0
@@ -539,8 +542,8 @@ def _bsgmp_infer(h, pos, plans, ews, hidden, params, session=None):
     else:
         work = _workspace(h.device, nbytes)
     pp, keep = _param_ptrs(params)
-    _abi.check(L.bsms_bsgmp_fwd_ex(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
-                                   out.data_ptr(), None, work.data_ptr(), reuse, _stream()), "bsms_bsgmp_fwd(inference)")
+    _abi.check(L.bsms_bsgmp_fwd_p(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
+                                  out.data_ptr(), None, work.data_ptr(), reuse, prec, _stream()), "bsms_bsgmp_fwd(inference)")
     return out
 
 
@@ -559,6 +562,9 @@ class BSGMP(nn.Module):
         self.unet_depth = unet_depth
         self.latent_dim, self.pos_dim = latent_dim, pos_dim
         self.per_block = _PY_BSGMP   # True: one autograd node per block / transition (module tree) instead of one call
+        # "f32": the reference's arithmetic.  "bf16" (one-call path only): edge-level tensors stored as bf16, bf16 operands
+        # in the edge MLP, fp32 accumulation and fp32 everywhere at node level (include/bsms_hip.h: bsms_precision)
+        self.precision = os.environ.get("BSMS_PRECISION", "f32")
         self.edge_conv = WeightedEdgeConv()
         for _ in range(unet_depth):
             self.down_gmps.append(GMP(latent_dim, hidden_layer, pos_dim))
@@ -617,11 +623,14 @@ class BSGMP(nn.Module):
             all_plans = [*plans, bottom_plan]
             params = self.block_params()
             hidden = self.bottom_gmp.hidden_layer
+            prec = PRECISIONS[self.precision]
             if _needs_grad(h, *params):
-                y = _BSGMPFunction.apply(h, pos, all_plans, ews, hidden, *params)
+                y = _BSGMPFunction.apply(h, pos, all_plans, ews, hidden, prec, *params)
             else:
-                y = _bsgmp_infer(h, pos, all_plans, ews, hidden, params, session)
+                y = _bsgmp_infer(h, pos, all_plans, ews, hidden, params, session, prec)
             return y.squeeze(0) if squeeze else y
+        if self.precision != "f32":
+            raise NotImplementedError("the bf16 precision exists on the one-call U-Net path only (BSGMP.per_block = False)")
         for i in range(L):
             plan = plans[i]
             h = self.down_gmps[i](h, m_gs[i], pos, plan=plan)

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import _abi
-from .ops import _param_ptrs, _stream
+from .ops import PRECISIONS, _param_ptrs, _stream
 
 
 def _ptr(t):
@@ -73,7 +73,7 @@ class FusedStep:
     def _buffers(self, B, N, plans, dev):
         m, L = self.model, _abi.lib()
         C, p, D, H = m.cfg.out_dim, m.pos_dim, m.cfg.latent_dim, m.cfg.hidden_layer
-        key = (B, N, tuple(id(q) for q in plans), str(dev))
+        key = (B, N, tuple(id(q) for q in plans), str(dev), m.process.precision)
         if key == self._shape_key:
             return self._buf
         R, depth = B * N, len(plans) - 1
@@ -84,7 +84,8 @@ class FusedStep:
                  norm_in=f(R, C + 1), pos=f(R, p), h0=f(R, D), h1=f(R, D), norm_pred=f(R, C), pred=f(B, N, C),
                  sums=f(2), loss=f(1), g_np=f(R, C), gh1=f(R, D), gh0=f(R, D),
                  s_enc=u8(L.bsms_mlp_saved_bytes(R, C + 1, D, D, H)), s_dec=u8(L.bsms_mlp_saved_bytes(R, D, D, C, H)),
-                 s_proc=u8(L.bsms_bsgmp_saved_bytes(pl, depth, B, D, p, H)),
+                 s_proc=u8(L.bsms_bsgmp_saved_bytes_p(pl, depth, B, D, p, H, PRECISIONS[m.process.precision])),
+                 prec=m.process.precision,
                  work=u8(max(L.bsms_mlp_work_bytes(R, C + 1, D, D, H), L.bsms_mlp_work_bytes(R, D, D, C, H),
                              L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, H), L.bsms_sim_work_bytes(R))),
                  in_static=None)
@@ -104,8 +105,8 @@ class FusedStep:
         ck(L.bsms_mlp_fwd(b["norm_in"].data_ptr(), R, C + 1, D, D, H, 1, t["enc"][0][0], b["h0"].data_ptr(), b["s_enc"].data_ptr(),
                           work.data_ptr(), s), "bsms_mlp_fwd(encode)")
         ewp, keep = _abi.ptr_array([e.data_ptr() for e in ews])
-        ck(L.bsms_bsgmp_fwd(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), B, D, p, N * p, H, t["proc"][0][0],
-                            b["h1"].data_ptr(), b["s_proc"].data_ptr(), work.data_ptr(), s), "bsms_bsgmp_fwd")
+        ck(L.bsms_bsgmp_fwd_p(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), B, D, p, N * p, H, t["proc"][0][0],
+                              b["h1"].data_ptr(), b["s_proc"].data_ptr(), work.data_ptr(), 0, PRECISIONS[b["prec"]], s), "bsms_bsgmp_fwd")
         ck(L.bsms_mlp_fwd(b["h1"].data_ptr(), R, D, D, C, H, 0, t["dec"][0][0], b["norm_pred"].data_ptr(), b["s_dec"].data_ptr(),
                           work.data_ptr(), s), "bsms_mlp_fwd(decode)")
         ck(L.bsms_sim_epilogue(b["norm_pred"].data_ptr(), node_in.data_ptr(), mask.data_ptr(), tar.data_ptr(), R, C, p,
@@ -125,9 +126,9 @@ class FusedStep:
         ck(L.bsms_mlp_bwd(b["h1"].data_ptr(), b["g_np"].data_ptr(), R, D, D, C, H, 0, t["dec"][0][0], b["s_dec"].data_ptr(),
                           work.data_ptr(), b["gh1"].data_ptr(), t["dec"][1][0], s), "bsms_mlp_bwd(decode)")
         ewp, keep = _abi.ptr_array([e.data_ptr() for e in ews])
-        ck(L.bsms_bsgmp_bwd(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), b["gh1"].data_ptr(), B, D, p, N * p, H,
-                            t["proc"][0][0], b["s_proc"].data_ptr(), work.data_ptr(), b["gh0"].data_ptr(), t["proc"][1][0], s),
-           "bsms_bsgmp_bwd")
+        ck(L.bsms_bsgmp_bwd_p(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), b["gh1"].data_ptr(), B, D, p, N * p, H,
+                              t["proc"][0][0], b["s_proc"].data_ptr(), work.data_ptr(), b["gh0"].data_ptr(), t["proc"][1][0],
+                              PRECISIONS[b["prec"]], s), "bsms_bsgmp_bwd")
         ck(L.bsms_mlp_bwd(b["norm_in"].data_ptr(), b["gh0"].data_ptr(), R, C + 1, D, D, H, 1, t["enc"][0][0], b["s_enc"].data_ptr(),
                           work.data_ptr(), None, t["enc"][1][0], s), "bsms_mlp_bwd(encode)")
 

@@ -48,6 +48,14 @@ typedef enum {
   BSMS_E_HIP = -4
 } bsms_status;
 
+/* Precision of the EDGE-level tensors inside a GMP block (the *_p entries of the U-Net).  BSMS_F32 is the reference's
+ * arithmetic.  BSMS_BF16 is a build extension without a reference parity target (the reference has no mixed precision):
+ * the saved edge activations, the messages and the edge layer gradients are stored in HBM as bf16 (round to nearest
+ * even) and the D x D Linears of the edge MLP multiply bf16 operands (weights rounded once per call) with fp32
+ * accumulation; bias, ReLU, LayerNorm, the aggregation sums, every node-level tensor and kernel (projections, node
+ * MLP, transitions, skip connections), the encoder / decoder and all weight-gradient accumulators stay fp32. */
+typedef enum { BSMS_F32 = 0, BSMS_BF16 = 1 } bsms_precision;
+
 typedef struct bsms_plan bsms_plan_t; /* one mesh level: dst-sorted CSR + src-sorted transpose */
 typedef void* bsms_stream_t;          /* hipStream_t */
 
@@ -85,6 +93,10 @@ int bsms_segment_sum_fwd(const bsms_plan_t* plan, const float* src, int64_t B, i
                          int plan_order, float* out, bsms_stream_t stream);
 int bsms_segment_sum_bwd(const bsms_plan_t* plan, const float* grad_out, int64_t B, int64_t D,
                          float* grad_src, bsms_stream_t stream);
+/* The aggregation of the BSMS_BF16 precision: `src_bf16` [B,E,D] bf16 in PLAN order (what the edge MLP of that precision
+ * writes), fp32 sums in edge order, fp32 out [B,N,D].  D = 128 or 256. */
+int bsms_segment_sum_bf16(const bsms_plan_t* plan, const void* src_bf16, int64_t B, int64_t D, float* out,
+                          bsms_stream_t stream);
 
 /* ---------------------------------------------------------------- A2+A6: cal_ew -------------
  * WeightedEdgeConv.cal_ew (ops/basic.py:142-167) incl. degree() (utils/basic.py:287-309):
@@ -166,6 +178,15 @@ int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* const* ew, int 
 int bsms_bsgmp_fwd_ex(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
                       int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                       const float* const* params, float* out, void* saved, void* work, int reuse, bsms_stream_t stream);
+/* The U-Net with a choice of precision (see bsms_precision): sizes, forward (+ reuse flags) and backward. */
+size_t bsms_bsgmp_saved_bytes_p(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden, int precision);
+int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                     int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden, const float* const* params,
+                     float* out, void* saved, void* work, int reuse, int precision, bsms_stream_t stream);
+int bsms_bsgmp_bwd_p(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                     const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                     const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
+                     int precision, bsms_stream_t stream);
 int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
                    const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                    const float* const* params, const void* saved, void* work, float* grad_h,

@@ -1,0 +1,155 @@
+"""GPU: the BSMS_BF16 precision of the U-Net (include/bsms_hip.h: bsms_precision; BASELINE.json configs[2] and [4]).
+
+The reference has no mixed precision, so this mode has NO reference parity target; what is pinned instead:
+  * SEMANTICS: against a CPU emulation of the documented arithmetic -- the oracle's GMP with (a) the weights of the
+    D x D Linears of the edge MLP rounded to bf16, (b) the activation entering each of those Linears rounded to bf16,
+    (c) the messages rounded to bf16 before the aggregation, everything else fp32.  Forward tolerance 3e-3 of the tensor
+    scale (an activation that sits within fp32 round-off of a bf16 rounding boundary may round the other way: one
+    such element moves an output by ~2^-9 of one product).
+  * ACCURACY vs the fp32 oracle (what a user trades): prediction <= 3e-2 of the tensor scale, loss <= 1e-2, every
+    parameter gradient within 8e-2 relative L2 of the fp32 gradient and cosine >= 0.995 (bf16 has 8 significand bits:
+    2^-9 = 2e-3 per rounding, ~10 roundings deep per block, 3-11 blocks).
+  * the fused (no autograd) step and the autograd step agree in bf16 mode as they do in fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import bsms_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import bsms_gnn_amd as eng
+    return eng
+
+
+def bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class EmulatedGMP(ro.GMP):
+    """ro.GMP with the documented bf16 roundings of the edge MLP (ops/basic.py:90-94 is where they act)."""
+
+    def forward(self, x, g, pos):
+        send, recv = g[0], g[1]
+        rel = ro._take_nodes(pos, send) - ro._take_nodes(pos, recv)
+        fiber = torch.cat([rel, torch.norm(rel, dim=-1, keepdim=True)], -1)
+        if x.dim() == 3 and pos.dim() == 2:
+            fiber = fiber.unsqueeze(0).repeat(x.shape[0], 1, 1)
+        seq = self.mlp_edge.seq
+        a = torch.relu(seq[0](torch.cat([fiber, ro._take_nodes(x, send), ro._take_nodes(x, recv)], -1)))   # first Linear: fp32 (node projections)
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)][1:]
+        for k, m in enumerate(lin):
+            a = torch.nn.functional.linear(bf16(a), bf16(m.weight), m.bias)
+            if k < len(lin) - 1:
+                a = torch.relu(a)
+        msg = bf16(torch.nn.functional.layer_norm(a, a.shape[-1:]))
+        aggr = ro.scatter_sum(msg, recv, dim=-2, dim_size=x.shape[-2])
+        return self.mlp_node(torch.cat([x, aggr], -1)) + x
+
+
+def emulate(net):
+    for name, mod in list(net.named_modules()):
+        if type(mod) is ro.GMP:
+            mod.__class__ = EmulatedGMP
+    return net
+
+
+def test_bf16_forward_matches_the_documented_arithmetic(eng, graphs):
+    es, ids = graphs.levels("del300")
+    torch.manual_seed(0)
+    for depth in (0, 2):
+        ref = ro.BSGMP(depth, 128, 3, 2)
+        mine = eng.BSGMP(depth, 128, 3, 2)
+        mine.load_state_dict(ref.state_dict())
+        mine = mine.cuda()
+        mine.precision = "bf16"
+        h, pos = torch.randn(2, 300, 128), graphs.t("del300/pos").float().unsqueeze(0).repeat(2, 1, 1)
+        with torch.no_grad():
+            want32 = ref(h, ids[:depth], es[: depth + 1], pos)
+            want = emulate(ref)(h, ids[:depth], es[: depth + 1], pos)
+            got = mine(h.cuda(), [i.cuda() for i in ids[:depth]], [e.cuda() for e in es[: depth + 1]], pos.cuda()).cpu()
+        assert rel_err(got, want) < 3e-3, depth
+        assert 1e-4 < rel_err(got, want32) < 3e-2, depth          # it really is a different precision, and a usable one
+        # training forward (activations saved as bf16) == inference forward, bit for bit
+        hh = h.cuda().requires_grad_(True)
+        y = mine(hh, [i.cuda() for i in ids[:depth]], [e.cuda() for e in es[: depth + 1]], pos.cuda())
+        assert torch.equal(y.detach().cpu(), got)
+        y.square().mean().backward()
+        assert torch.isfinite(hh.grad).all() and float(hh.grad.abs().max()) > 0
+
+
+def _grads_close(got, want, tag):
+    worst_l2, worst_cos = 0.0, 1.0
+    for k in want:
+        a, b = got[k].double().flatten(), want[k].double().flatten()
+        l2 = float((a - b).norm() / b.norm().clamp_min(1e-300))
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        worst_l2, worst_cos = max(worst_l2, l2), min(worst_cos, cos)
+    print(f"[{tag}] gradients vs fp32: worst relative L2 {worst_l2:.3e}, worst cosine {worst_cos:.5f}")
+    assert worst_l2 < 8e-2 and worst_cos > 0.995, (tag, worst_l2, worst_cos)
+
+
+def test_bf16_training_step_accuracy_vs_fp32_oracle(eng, graphs):
+    """One simulator step (forward + masked RMSE + backward) in bf16 precision against the fp32 CPU oracle."""
+    z = load_golden("sim")
+    es, ids = graphs.levels("del300")
+    B = z.np("node_in").shape[0]
+    cfg = ro.make_cfg(2, 128, 3, 3, 2)
+    torch.manual_seed(1)
+    ref = ro.BSMS_Simulator(cfg)
+    m_gs, m_ids = [e.unsqueeze(0).repeat(B, 1, 1) for e in es], [i.unsqueeze(0).repeat(B, 1) for i in ids]
+    data = (z.t("node_in"), z.t("tar"), z.t("mask"), m_gs, m_ids)
+    ref(data, True, True)
+    pred_ref = ref(data, True, False)
+    loss_ref = ro.masked_rmse(pred_ref, data[1], data[2])
+    loss_ref.backward()
+    want = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    mine = eng.BSMS_Simulator(cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda()
+    mine.process.precision = "bf16"
+    gdata = (data[0].cuda(), data[1].cuda(), data[2].cuda(), [g.cuda() for g in m_gs], [i.cuda() for i in m_ids])
+    pred = mine(gdata, True, False)
+    loss = eng.masked_rmse(pred, gdata[1], gdata[2])
+    loss.backward()
+    assert rel_err(pred.detach().cpu(), pred_ref.detach()) < 3e-2
+    assert abs(float(loss) - float(loss_ref)) < 1e-2 * abs(float(loss_ref))
+    got = {k: p.grad.cpu() for k, p in mine.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    _grads_close(got, want, "del300 L=3 D=128 bf16")
+    # fused step == autograd step in this precision too
+    auto = {k: v.clone() for k, v in got.items()}
+    mine.zero_grad(set_to_none=True)
+    grads = eng.GradBuckets(list(mine.parameters()))
+    step = eng.FusedStep(mine, grads)
+    l2 = step(gdata, True)
+    assert abs(float(l2) - float(loss)) < 1e-6 * abs(float(loss))
+    for k, p in mine.named_parameters():
+        if p.requires_grad:
+            assert rel_err(p.grad.cpu(), auto[k]) < 2e-5, k
+
+
+def test_bf16_airfoil_full_size_vs_fp32_engine(eng):
+    """BASELINE configs[2] (airfoil B=8, 5 levels, D=128, bf16): same model, same batch, bf16 precision against the fp32
+    engine (itself pinned to the oracle by tests/test_hip_fullsize.py)."""
+    from bench import build_workload, data_tuple, make_cfg
+    wl = build_workload("airfoil", 8, "cuda")
+    torch.manual_seed(0)
+    sim = eng.BSMS_Simulator(make_cfg(wl["cfg"])).cuda()
+    data = data_tuple(wl)
+    sim(data, True, True)
+    res = {}
+    for prec in ("f32", "bf16"):
+        sim.process.precision = prec
+        sim.zero_grad(set_to_none=True)
+        pred = sim(data, True, False)
+        loss = eng.masked_rmse(pred, data[1], data[2])
+        loss.backward()
+        res[prec] = (pred.detach().clone(), float(loss), {k: p.grad.clone() for k, p in sim.named_parameters() if p.grad is not None})
+    assert rel_err(res["bf16"][0], res["f32"][0]) < 3e-2
+    assert abs(res["bf16"][1] - res["f32"][1]) < 1e-2 * abs(res["f32"][1])
+    _grads_close(res["bf16"][2], res["f32"][2], "airfoil B=8 L=5 D=128 bf16 vs fp32 engine")
