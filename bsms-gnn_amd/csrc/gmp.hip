@@ -369,7 +369,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     scope1.lane = lane;
   }
   {
-    WgradJob jobs[kMaxWgradJobs];
+    WgradJob jobs[kMaxWgradJobs] = {};
     int nj = 0;
     auto add_job = [&](const float* G, const float* A, float* dW, float* db, int64_t R, int ldw, int col0) {
       WgradJob& j = jobs[nj++];
@@ -414,7 +414,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   if (overlap2 && (rc = side_fork(lane2, s))) return rc;   // lane 2 additionally waits for dPs / dPd (and the partials)
   if (nwg > 0 && (rc = launch_small_reduce(sw, wk.sw, nwg, s2))) return rc;
   {
-    WgradJob jobs[2];
+    WgradJob jobs[2] = {};
     auto set = [&](WgradJob& j, const float* G, int col0) {
       j.G = G; j.A = x; j.dW = ge[0]; j.db = nullptr; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldE0; j.col0 = col0; j.bf16 = 0;
     };
@@ -587,7 +587,7 @@ extern "C" int bsms_mlp_bwd(const float* x, const float* grad_y, int64_t R, int6
   }
   if (rc) return rc;
 
-  WgradJob jobs[kMaxWgradJobs];
+  WgradJob jobs[kMaxWgradJobs] = {};
   int nj = 0;
   for (int l = (kind == MLP_SMALL_LN ? 1 : 0); l <= top; ++l) {
     WgradJob& j = jobs[nj++];

@@ -83,13 +83,16 @@ def test_bf16_forward_matches_the_documented_arithmetic(eng, graphs):
 
 
 def _grads_close(got, want, tag):
-    worst_l2, worst_cos = 0.0, 1.0
+    worst_l2, worst_cos, rows = 0.0, 1.0, []
     for k in want:
         a, b = got[k].double().flatten(), want[k].double().flatten()
         l2 = float((a - b).norm() / b.norm().clamp_min(1e-300))
         cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300))
         worst_l2, worst_cos = max(worst_l2, l2), min(worst_cos, cos)
-    print(f"[{tag}] gradients vs fp32: worst relative L2 {worst_l2:.3e}, worst cosine {worst_cos:.5f}")
+        rows.append((l2, cos, k))
+    rows.sort(reverse=True)
+    print(f"[{tag}] gradients vs fp32: worst relative L2 {worst_l2:.3e}, worst cosine {worst_cos:.5f}, median L2 "
+          f"{float(np.median([r[0] for r in rows])):.3e}; worst tensors: " + ", ".join(f"{k} {l2:.2e}" for l2, _, k in rows[:5]))
     assert worst_l2 < 8e-2 and worst_cos > 0.995, (tag, worst_l2, worst_cos)
 
 
