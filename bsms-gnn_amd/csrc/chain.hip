@@ -1,6 +1,4 @@
 // Chain kernels (see chain.h for the register-layout idea) + weight prepack.
-#include <cstdlib>
-
 #include "chain.h"
 
 using namespace bsms;
@@ -224,20 +222,14 @@ __device__ __forceinline__ float row_sum(const f32x4 (&v)[NB]) {
 // until its activation stores had reached memory -- MFMA phases and HBM phases then add up instead of
 // overlapping (measured: kernel time = MFMA time + store time).  Compute waves execute NO vmcnt wait in the
 // steady state; their stores drain in the background.
-// NR_ = 3: the standard ring (two workgroups per CU at D = 128, one loader wave, two chunks in flight).
-// NR_ = 6: the DEEP ring for launches that fit one round of workgroups (coarse mesh levels, node-level chains): one
-//          workgroup per CU owns 154 KB of LDS, TWO loader waves split every chunk (13 + 12 LDS-DMA instructions, so five
-//          chunks in flight still fit the 6-bit vmcnt) -- a lone tile then waits for one L2 latency per five chunks
-//          instead of one per two (the 26 us floor of a four-Linear chain).
-template <int NB, int NR_ = 3>
+template <int NB>
 struct Ring {
   static constexpr int D = NB * 16;
   static constexpr int NCH = NB / 2;                          // chunks per stage (one per 32-feature K block)
   static constexpr int CHF = kChunkHdrFloats + NB * 768;      // floats per chunk
   static constexpr int CH4 = CHF / 4;                         // float4 per chunk
   static constexpr int PER = CHF / 256;                       // LDS-DMA instructions (1 KB each) per chunk
-  static constexpr int NR = NR_;                              // ring depth
-  static constexpr int NL = NR_ == 3 ? 1 : 2;                 // loader waves
+  static constexpr int NR = 3;                                // ring depth
   static constexpr int SIDE_FLOATS = 8 * D;                   // side table after the ring: the edge MLP's fiber weights
   static constexpr size_t lds_bytes = size_t(NR) * CHF * sizeof(float) + SIDE_FLOATS * sizeof(float);
   static_assert(CHF % 256 == 0 && PER < 64, "chunk = whole LDS-DMA instructions, countable by vmcnt");
@@ -256,28 +248,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 }
 
 // the loader wave's whole life
-template <int NB, int NR = 3>
-__device__ __forceinline__ float* ring_side(float4* lds) { return reinterpret_cast<float*>(lds + Ring<NB, NR>::NR * Ring<NB, NR>::CH4); }
+template <int NB>
+__device__ __forceinline__ float* ring_side(float4* lds) { return reinterpret_cast<float*>(lds + Ring<NB>::NR * Ring<NB>::CH4); }
 
 // `side` (nullable, 8*D floats in HBM): copied once into the side table; the compute waves wait for it at one extra
-// barrier before their first tile.  `LW`: index of this loader wave (0 .. NL-1); wave LW moves LDS-DMA instructions
-// LW, LW + NL, ... of every chunk, and every loader wave takes part in every barrier.
-template <int NB, int NR, int LW>
+// barrier before their first tile.
+template <int NB>
 __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles,
                                            const float* side = nullptr) {
-  using R = Ring<NB, NR>;
-  constexpr int NL = R::NL;
-  constexpr int CW = (R::PER - LW + NL - 1) / NL;     // my instructions per chunk
-  constexpr int AHEAD = NR - 1;                       // chunks in flight
-  static_assert((AHEAD - 1) * CW < 64, "younger chunks must be countable by vmcnt");
+  using R = Ring<NB>;
   __builtin_amdgcn_s_setprio(3);                   // the loader must never be the wave the others wait for
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
   if (side) {
-    if (LW == 0) {
-      const unsigned dst = lds0 + unsigned(R::NR) * unsigned(R::CHF * sizeof(float));
+    const unsigned dst = lds0 + unsigned(R::NR) * unsigned(R::CHF * sizeof(float));
 #pragma unroll
-      for (int i = 0; i < R::SIDE_FLOATS / 256; ++i) glds16(reinterpret_cast<const float4*>(side) + i * 64 + lane, dst + i * 1024);
-    }
+    for (int i = 0; i < R::SIDE_FLOATS / 256; ++i) glds16(reinterpret_cast<const float4*>(side) + i * 64 + lane, dst + i * 1024);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
   const int my_tiles = (ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
@@ -287,21 +272,18 @@ __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, 
     const float4* src = wseq[is] + size_t(ic) * R::CH4 + lane;
     const unsigned dst = lds0 + unsigned(islot) * unsigned(R::CHF * sizeof(float));
 #pragma unroll
-    for (int i = LW; i < R::PER; i += NL) glds16(src + i * 64, dst + i * 1024);
+    for (int i = 0; i < R::PER; ++i) glds16(src + i * 64, dst + i * 1024);
     if (++ic == R::NCH) { ic = 0; if (++is == nseq) is = 0; }
     if (++islot == R::NR) islot = 0;
   };
-  for (int k = 0; k < AHEAD && k < total; ++k) issue();
+  if (total > 0) issue();
+  if (total > 1) issue();
   for (int j = 0; j < total; ++j) {
-    // chunk j has landed once at most the `young` younger chunks (whole, my share of each) are still outstanding
-    const int young = min(AHEAD - 1, total - 1 - j);
-    if (young >= 4 && AHEAD > 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD > 4 ? 4 : 0) * CW) : "memory");
-    else if (young == 3 && AHEAD > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD > 3 ? 3 : 0) * CW) : "memory");
-    else if (young == 2 && AHEAD > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD > 2 ? 2 : 0) * CW) : "memory");
-    else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
+    // chunk j has landed once at most the (whole) younger chunk is still outstanding
+    if (j + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R::PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");       // barrier #j: publishes chunk j; everyone is done with chunk j-1,
-    if (j + AHEAD < total) issue();                // whose slot chunk j+AHEAD now overwrites
+    if (j + 2 < total) issue();                    // whose slot chunk j+2 now overwrites
   }
 }
 
@@ -341,12 +323,12 @@ __device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
 // right after the split so the store has the whole stage to drain.  All compute waves of the workgroup must call this together.
 // BF (bf16 precision, chain.h): operands are the bf16 roundings of `act` and of the weights (plane 0 of the pack holds
 // the rounded weight, the other planes are unused), ONE product per fragment pair; `store_base` receives bf16 rows.
-template <int NB, bool TIMED = false, bool BF = false, int NR = 3>
+template <int NB, bool TIMED = false, bool BF = false>
 __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
                                            bool from_header, float* store_base = nullptr, int64_t store_off = -1,
                                            int store_mode = 0, int64_t mask_rows = 0,
                                            unsigned long long* waited = nullptr, int64_t row = 0, int64_t nrows = 0) {
-  using R = Ring<NB, NR>;
+  using R = Ring<NB>;
   if constexpr (BF) {
     u32x4 bb[NB / 2];
     round_block<NB>(act, 0, bb[0]);
@@ -481,15 +463,13 @@ __device__ __forceinline__ float dot_features(const f32x4 (&v)[NB], const float*
 // -------------------------------------------------------------------------------- forward chain
 // TIMING (experiments, profiles/tile_timeline.py): phase stamps of wave 0; a separate instantiation so that the
 // production kernel carries none of it.
-template <int NB, int IN, int OUT, bool TIMING = false, bool BF = false, int NR = 3>
-__global__ __launch_bounds__((kComputeWaves + Ring<NB, NR>::NL) * 64) __attribute__((amdgpu_waves_per_eu(NB <= 8 && NR == 3 ? 4 : 2)))
-void k_chain_fwd(ChainFwdArgs a) {
+template <int NB, int IN, int OUT, bool TIMING = false, bool BF = false>
+__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  if (wave >= kComputeWaves) {  // loader wave(s) (uniform branch)
-    if (wave == kComputeWaves) loader_run<NB, NR, 0>(a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
-    else loader_run<NB, NR, Ring<NB, NR>::NL - 1>(a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
+  if (wave == kComputeWaves) {  // loader wave (uniform branch)
+    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
     return;
   }
   // IN_EDGE: the fiber weights are read from the LDS side table (read from HBM/L2 they cost one dependent round
@@ -497,7 +477,7 @@ void k_chain_fwd(ChainFwdArgs a) {
   const float* w0t = a.w0t;
   if (IN == IN_EDGE) {
     lds_barrier();
-    w0t = ring_side<NB, NR>(lds);
+    w0t = ring_side<NB>(lds);
   }
   int slot = 0;  // ring slot of the next chunk; runs on across this workgroup's tiles exactly like the loader's
   // Persistent workgroups: the grid is sized to what the chip holds at once and strides over the tiles, so a CU
@@ -580,20 +560,20 @@ void k_chain_fwd(ChainFwdArgs a) {
     store_mask_bits<NB>(act, pending, a.R, roff, lg);
   }
   if (OUT == OUT_PLAIN2) {  // two Linears of the SAME rows (the edge MLP's two node projections): one launch, one read of x
-    mfma_stage<NB, false, false, NR>(acc, act, lds, slot, lane, true);
+    mfma_stage<NB>(acc, act, lds, slot, lane, true);
     store_rows<NB, false>(acc, a.y, roff, lg);
-    mfma_stage<NB, false, false, NR>(acc, act, lds, slot, lane, true);
+    mfma_stage<NB>(acc, act, lds, slot, lane, true);
     store_rows<NB, false>(acc, a.y2, roff, lg);
     continue;
   }
   for (int l = 0; l < a.nstage; ++l) {
-    mfma_stage<NB, TIMING, BF, NR>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode & 3, (a.store_mode & 4) ? 0 : a.R, &waited,
+    mfma_stage<NB, TIMING, BF>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode & 3, (a.store_mode & 4) ? 0 : a.R, &waited,
                                row, (a.store_mode & 8) ? 0 : a.R);  // acc = bias + W act
     stamp();          // stage l done
     pending = nullptr;
     if (IN == IN_ROWS2 && l == 0) {
       load_rows<NB>(act, a.x2 + rowc * D, lg);
-      mfma_stage<NB, false, false, NR>(acc, act, lds, slot, lane, false);
+      mfma_stage<NB>(acc, act, lds, slot, lane, false);
     }
     const bool last = (l == a.nstage - 1);
     if (!last || OUT == OUT_SMALL) {
@@ -673,15 +653,13 @@ __device__ __forceinline__ void mask_by(f32x4 (&gr)[NB], const float* act_row, i
   }
 }
 
-template <int NB, int GIN, int FIRST, bool BF = false, int NR = 3>
-__global__ __launch_bounds__((kComputeWaves + Ring<NB, NR>::NL) * 64) __attribute__((amdgpu_waves_per_eu(NB <= 8 && NR == 3 ? 4 : 2)))
-void k_chain_bwd(ChainBwdArgs a) {
+template <int NB, int GIN, int FIRST, bool BF = false>
+__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  if (wave >= kComputeWaves) {  // loader wave(s) (uniform branch)
-    if (wave == kComputeWaves) loader_run<NB, NR, 0>(a.wseq, a.nseq, lds, lane, a.ntiles);
-    else loader_run<NB, NR, Ring<NB, NR>::NL - 1>(a.wseq, a.nseq, lds, lane, a.ntiles);
+  if (wave == kComputeWaves) {  // loader wave (uniform branch)
+    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles);
     return;
   }
   int slot = 0;  // ring slot of the next chunk, across this workgroup's tiles
@@ -735,7 +713,7 @@ void k_chain_bwd(ChainBwdArgs a) {
       mbits[w] = a.mask[k] ? reinterpret_cast<const unsigned*>(a.mask[k] + (BF ? a.R * D / 2 : a.R * D))[rowc * (4 * mask_words<NB>()) + lg * mask_words<NB>() + w]
                            : 0xffffffffu;
     zero_tile<NB>(acc);
-    mfma_stage<NB, false, BF, NR>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode & 3, 0, nullptr, row, (a.store_mode & 8) ? 0 : a.R);
+    mfma_stage<NB, false, BF>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode & 3, 0, nullptr, row, (a.store_mode & 8) ? 0 : a.R);
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
@@ -745,7 +723,7 @@ void k_chain_bwd(ChainBwdArgs a) {
 
   if (FIRST != F_NONE) {
     zero_tile<NB>(acc);
-    mfma_stage<NB, false, false, NR>(acc, g, lds, slot, lane, false, pending, roff);
+    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff);
     pending = nullptr;
     if (a.dres) {
       f32x4 r[NB];
@@ -756,7 +734,7 @@ void k_chain_bwd(ChainBwdArgs a) {
     if (FIRST == F_HEADS2) {
       f32x4 acc2[NB];
       zero_tile<NB>(acc2);
-      mfma_stage<NB, false, false, NR>(acc2, g, lds, slot, lane, false);
+      mfma_stage<NB>(acc2, g, lds, slot, lane, false);
       store_rows<NB, false>(acc, a.dx, roff, lg);
       store_rows<NB, false>(acc2, a.dx2, roff, lg);
     } else {
@@ -773,22 +751,6 @@ void k_chain_bwd(ChainBwdArgs a) {
 // profiles/census).  A grid larger than the residency would only queue, a smaller one idles slots.
 template <int NB>
 constexpr int resident_per_cu() { return NB <= 4 ? 4 : NB == 8 ? 2 : 1; }
-
-int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
-// tile count up to which a launch uses the deep ring: one workgroup per tile, at most one per CU
-int deep_ring_tiles() {
-  static const int off = getenv("BSMS_NO_DEEP_RING") ? 1 : 0;   // A/B switch (read once)
-  return off ? 0 : device_cus();
-}
 
 template <int NB>
 unsigned persistent_grid(int64_t ntiles) {
@@ -835,17 +797,6 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
     }
   }
   BSMS_REQUIRE(launched || !a.bf16, BSMS_E_UNSUPPORTED, "chain_fwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
-  if constexpr (NB == 8) {   // launches that fit one round of workgroups: the deep ring (one workgroup per CU, two loader waves)
-    if (!launched && a.ntiles <= deep_ring_tiles()) {
-      using RD = Ring<NB, 6>;
-      static const hipError_t dattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, false, 6>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)RD::lds_bytes);
-      BSMS_REQUIRE(dattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve %zu bytes of LDS (deep ring)", RD::lds_bytes);
-      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, false, 6>), dim3((unsigned)a.ntiles), dim3((kComputeWaves + RD::NL) * 64),
-                         RD::lds_bytes, s, a);
-      launched = true;
-    }
-  }
   if (!launched)
     hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
@@ -891,18 +842,6 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
     }
   }
   BSMS_REQUIRE(!a.bf16, BSMS_E_UNSUPPORTED, "chain_bwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
-  if constexpr (NB == 8) {
-    if (a.ntiles <= deep_ring_tiles()) {
-      using RD = Ring<NB, 6>;
-      static const hipError_t dattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, false, 6>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)RD::lds_bytes);
-      BSMS_REQUIRE(dattr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS (deep ring)", RD::lds_bytes);
-      hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, false, 6>), dim3((unsigned)a.ntiles), dim3((kComputeWaves + RD::NL) * 64),
-                         RD::lds_bytes, s, a);
-      BSMS_LAUNCH_CHECK();
-      return BSMS_OK;
-    }
-  }
   hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
