@@ -386,6 +386,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()                 # host cost of a step: enqueue 3 steps into an EMPTY queue, no synchronisation
+    for _ in range(3):
+        step()
+    host_ms = (time.perf_counter() - h0) / 3 * 1e3
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -420,6 +425,7 @@ def main():
                                    + ("consistent mesh" if consistent else "block-diagonal batch of different meshes"),
                        "levels_N_E": wl["levels"], "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "trainable_params": n_params, "loss": float(loss.detach())},
+            "host_enqueue_ms_per_step": host_ms,
         }
         if world == 1 and not args.no_roofline and consistent:
             line["roofline"], line["roofline_mfma"] = roofline_objects(wl, args.batch, args.dtype)

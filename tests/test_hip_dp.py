@@ -69,3 +69,26 @@ def test_two_ranks_equal_single_process_large_batch(tmp_path):
     # summed per-rank gradients == gradient of the single-process batch-2 step recorded in the golden file
     want = torch.cat([z.t("g/" + k).reshape(-1) for k in r0["slot_names"]])
     assert rel_err(r0["flat"], want) < 2e-5
+
+
+@pytest.mark.timeout(600)
+def test_bench_n2_path_with_gloo_on_one_gpu(tmp_path):
+    """bench.py's own N > 1 path (one process per rank under torch.distributed.run, barrier + max-over-ranks timing, the
+    two collectives of FusedStep) with gloo on one GPU -- RCCL needs a GPU per rank, the multi-GPU run is the driver's.
+    Checks the JSON contract and prints the host enqueue time per step of rank 0 (8 ranks share one host)."""
+    import json
+    import subprocess
+    env = dict(os.environ, BSMS_DIST_BACKEND="gloo", BSMS_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--workload", "cylinder"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert "roofline" not in line and "cpu_baseline" not in line            # N = 1 only
+    print(f"\nbench --gpus 2 (gloo, one GPU): {line['value']:.1f} steps/s aggregate, host enqueue "
+          f"{line['host_enqueue_ms_per_step']:.2f} ms/step on rank 0, loss {line['config']['loss']:.6f}")
+    assert line["host_enqueue_ms_per_step"] < 6.0
