@@ -106,8 +106,11 @@ __device__ __forceinline__ void rowsum_body(const RowSumArgs& a) {
     if (DEEP)
       for (; q + 32 <= q1; q += 32) acc = rowsum_batch<32, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc);
     for (; q + 8 <= q1; q += 8) acc = rowsum_batch<8, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc);
-    for (; q + 2 <= q1; q += 2) acc = rowsum_batch<2, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc);
-    for (; q < q1; ++q) acc = rowsum_batch<1, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc);
+    // the remaining 1..7 slots as ONE batch of exactly that size: a fine-level row (6-7 edges) costs a single round
+    // trip to memory instead of three or four dependent ones; the additions keep their slot order
+#define BSMS_TAIL(K) case K: acc = rowsum_batch<K, WEIGHTED, MAPPED, HAS_XIDX, HAS_WIDX, XBF>(a, xcol, q, acc); break
+    switch (q1 - q) { BSMS_TAIL(7); BSMS_TAIL(6); BSMS_TAIL(5); BSMS_TAIL(4); BSMS_TAIL(3); BSMS_TAIL(2); BSMS_TAIL(1); default: break; }
+#undef BSMS_TAIL
     if (a.addend) {   // (row sum) + addend: one more rounded add, exactly what a separate elementwise add would do
       const float4 ad = *reinterpret_cast<const float4*>(a.addend + b * a.out_bstride + int64_t(r) * a.D + c4 * 4);
       acc.x += ad.x; acc.y += ad.y; acc.z += ad.z; acc.w += ad.w;
@@ -206,8 +209,10 @@ __global__ __launch_bounds__(256) void k_rowsum_pair_fiber(RowSumArgs a0, RowSum
     int q = q0;
     if (DEEP)
       for (; q + 16 <= q1; q += 16) fiber_batch<16, NS, XBF>(a.x, xcol, frow, a.D, ld, q, acc, accf);
-    for (; q + 4 <= q1; q += 4) fiber_batch<4, NS, XBF>(a.x, xcol, frow, a.D, ld, q, acc, accf);
-    for (; q < q1; ++q) fiber_batch<1, NS, XBF>(a.x, xcol, frow, a.D, ld, q, acc, accf);
+    for (; q + 8 <= q1; q += 8) fiber_batch<8, NS, XBF>(a.x, xcol, frow, a.D, ld, q, acc, accf);
+#define BSMS_TAIL(K) case K: fiber_batch<K, NS, XBF>(a.x, xcol, frow, a.D, ld, q, acc, accf); break
+    switch (q1 - q) { BSMS_TAIL(7); BSMS_TAIL(6); BSMS_TAIL(5); BSMS_TAIL(4); BSMS_TAIL(3); BSMS_TAIL(2); BSMS_TAIL(1); default: break; }
+#undef BSMS_TAIL
     *reinterpret_cast<float4*>(a.out + b * a.out_bstride + int64_t(r) * a.D + lane * 4) = acc;
     accs.x += acc.x; accs.y += acc.y; accs.z += acc.z; accs.w += acc.w;
   }
