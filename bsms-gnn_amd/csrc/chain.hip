@@ -369,8 +369,18 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
   // MFMAs (an MFMA occupies the issue port for 4 of its 16 cycles).
   u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
   split_block<NB>(act, 0, bh[0], bm[0], bl[0]);
+#ifdef BSMS_EXPERIMENTS
   const bool paired = (store_mode == 1 || store_mode == 2) && nrows > 0;   // saved tensors: 128-byte pieces, one pair per chunk
+  const bool streaming = store_mode == 1;
   if (!paired) store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
+#else
+  // production: a saved tensor is always written as streaming 128-byte pairs (callers pass nrows > 0 with every
+  // store_base); the store-mode switches exist in experiment builds only -- as run-time flags they put three variants
+  // of every store and their scalar branches into the hot loop
+  constexpr bool paired = true, streaming = true;
+  (void)store_mode;
+  if (nrows <= 0) store_base = nullptr;
+#endif
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     if (TIMED) {   // experiments: cycles this wave spends waiting at the chunk barriers
@@ -390,7 +400,7 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
         acc[t] = f32x4{x.x, x.y, x.z, x.w};
       }
     }
-    if (paired) store_pair_stream<NB>(act, store_base, row, nrows, lane, 2 * c, store_mode == 1);
+    if (paired) store_pair_stream<NB>(act, store_base, row, nrows, lane, 2 * c, streaming);
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
     // two accumulators interleaved so that back-to-back MFMAs are independent; one weight plane at a time (each
     // fragment pair is dead after its products: 8 fragment registers live + the next pair in flight)
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
 
   if (FIRST != F_NONE) {
     zero_tile<NB>(acc);
-    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff);
+    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff, 1, 0, nullptr, row, a.R);
     pending = nullptr;
     if (a.dres) {
       f32x4 r[NB];
