@@ -185,7 +185,11 @@ __device__ __forceinline__ void store_mask_bits(const f32x4 (&v)[NB], float* act
 #pragma unroll
     for (int k = 0; k < 32 && 32 * w + k < 4 * NB; ++k) {
       const int e = 32 * w + k;
-      m |= (v[e >> 2][e & 3] > 0.f) ? (1u << k) : 0u;
+      // `v` is a post-ReLU activation (>= +0): it is positive iff its bit pattern is non-zero -- min + shift-or, two
+      // operations per element instead of compare + select + or
+      unsigned b;
+      asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(v[e >> 2][e & 3])));   // (hipcc turns min(x, 1) into compare + select)
+      m |= b << k;
     }
     bits[w] = m;
   }
@@ -294,14 +298,20 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 // planes of K block kb2 (features 32 kb2 .. +31 of this lane's row)
 template <int NB>
 __device__ __forceinline__ void split_block(const f32x4 (&act)[NB], int kb2, u32x4& bh, u32x4& bm, u32x4& bl) {
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  using u2 = __attribute__((ext_vector_type(2))) unsigned;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {  // dword v = slots 2v, 2v+1 = act[2 kb2 + (v >> 1)][2 (v & 1) + {0, 1}]
-    unsigned h0, m0, l0, h1, m1, l1;
-    split3(act[2 * kb2 + (v >> 1)][2 * (v & 1)], h0, m0, l0);
-    split3(act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1], h1, m1, l1);
-    bh[v] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-    bm[v] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-    bl[v] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
+    // the same exact split as split3, two elements at a time: the residuals are packed subtractions (v_pk_add_f32),
+    // 9 VALU operations per pair instead of 11 -- the chain kernels are bound by the SIMD's issue port
+    const f2 x = {act[2 * kb2 + (v >> 1)][2 * (v & 1)], act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1]};
+    const u2 h = __builtin_bit_cast(u2, x) & 0xffff0000u;
+    const f2 r1 = x - __builtin_bit_cast(f2, h);
+    const u2 m = __builtin_bit_cast(u2, r1) & 0xffff0000u;
+    const u2 l = __builtin_bit_cast(u2, r1 - __builtin_bit_cast(f2, m));
+    bh[v] = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u);
+    bm[v] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+    bl[v] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
   }
 }
 
@@ -727,7 +737,10 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) g[t][r] = ((mbits[(4 * t + r) >> 5] >> ((4 * t + r) & 31)) & 1u) ? acc[t][r] : 0.f;
+      for (int r = 0; r < 4; ++r) {   // bit -> all-ones / zero mask (one v_bfe_i32), then one and
+        const int keep = __builtin_amdgcn_sbfe((int)mbits[(4 * t + r) >> 5], (4 * t + r) & 31, 1);
+        g[t][r] = __uint_as_float(__float_as_uint(acc[t][r]) & (unsigned)keep);
+      }
     pending = a.gstore[k + 1];
   }
 
