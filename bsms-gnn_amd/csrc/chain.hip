@@ -160,6 +160,13 @@ __device__ __forceinline__ void store_pair_stream(const f32x4 (&v)[NB], float* b
   got[3] = __builtin_amdgcn_update_dpp(own[3], own[3], 0x128, 0xf, 0xf, false);
   const f32x4 x = __builtin_bit_cast(f32x4, got);
   const f32x4 dA = hi ? x : v[t], dB = hi ? v[t] : x;
+#ifndef BSMS_EXPERIMENTS
+  // production: the tensor is allocated for whole tiles (chain.h: pad_rows), no bounds test and no exec-mask branches
+  (void)nrows;
+  __builtin_nontemporal_store(dA, reinterpret_cast<f32x4*>(pA));
+  __builtin_nontemporal_store(dB, reinterpret_cast<f32x4*>(pB));
+  return;
+#endif
   if (streaming) {
     if (rowA < nrows) __builtin_nontemporal_store(dA, reinterpret_cast<f32x4*>(pA));
     if (rowB < nrows) __builtin_nontemporal_store(dB, reinterpret_cast<f32x4*>(pB));
@@ -178,7 +185,7 @@ template <int NB, bool BF = false>
 __device__ __forceinline__ void store_mask_bits(const f32x4 (&v)[NB], float* act_base, int64_t R, int64_t off, int g) {
   if (!act_base || off < 0) return;
   constexpr int D = NB * 16, W = mask_words<NB>();
-  unsigned* bits = reinterpret_cast<unsigned*>(act_base + (BF ? R * D / 2 : R * D)) + (off / D) * (4 * W) + g * W;
+  unsigned* bits = reinterpret_cast<unsigned*>(act_base + (BF ? pad_rows(R) * D / 2 : pad_rows(R) * D)) + (off / D) * (4 * W) + g * W;
 #pragma unroll
   for (int w = 0; w < W; ++w) {
     unsigned m = 0;
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
     unsigned mbits[mask_words<NB>()];
 #pragma unroll
     for (int w = 0; w < mask_words<NB>(); ++w)
-      mbits[w] = a.mask[k] ? reinterpret_cast<const unsigned*>(a.mask[k] + (BF ? a.R * D / 2 : a.R * D))[rowc * (4 * mask_words<NB>()) + lg * mask_words<NB>() + w]
+      mbits[w] = a.mask[k] ? reinterpret_cast<const unsigned*>(a.mask[k] + (BF ? pad_rows(a.R) * D / 2 : pad_rows(a.R) * D))[rowc * (4 * mask_words<NB>()) + lg * mask_words<NB>() + w]
                            : 0xffffffffu;
     zero_tile<NB>(acc);
     mfma_stage<NB, false, BF>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode & 3, 0, nullptr, row, (a.store_mode & 8) ? 0 : a.R);

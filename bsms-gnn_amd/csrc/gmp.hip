@@ -75,7 +75,7 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
   Carver c(base);
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
-  const size_t edge_act = bf ? re * size_t(D) / 2 + re * mask_words_per_row(D) : act_floats(re, D);
+  const size_t edge_act = bf ? pad_rows(re) * size_t(D) / 2 + re * mask_words_per_row(D) : act_floats(re, D);
   if (training)
     for (int l = 0; l < H; ++l) s.e_act[l] = c.take(edge_act);
   s.e_y = c.take(bf ? re * D / 2 : re * D);
@@ -113,9 +113,9 @@ GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, i
   const size_t re = size_t(B) * E, rn = size_t(B) * N;
   w.Ps = c.take(rn * D); w.Pd = c.take(rn * D);
   w.dPs = w.Ps; w.dPd = w.Pd;  // the backward reuses the two projection buffers for their gradients
-  for (int l = 0; l <= H; ++l) w.gN[l] = c.take(rn * D);
+  for (int l = 0; l <= H; ++l) w.gN[l] = c.take(pad_rows(rn) * D);   // written tile-wise by the backward chains
   w.daggr = c.take(rn * D);
-  for (int l = 0; l <= H; ++l) w.gE[l] = c.take(re * D);
+  for (int l = 0; l <= H; ++l) w.gE[l] = c.take(pad_rows(re) * D);
   w.wg = c.take_bytes(wgrad_work_bytes((int)D, 0));
   w.wg2 = c.take_bytes(wgrad_work_bytes((int)D, 0));   // second split-K area: two wgrad launches run concurrently
   w.sw_bytes = small_wgrad_work_bytes_rows((int)D, B * N);   // one partial block per workgroup of the fused scatter kernel
@@ -472,7 +472,7 @@ struct MlpWork {
 MlpWork carve_mlp_work(void* base, int64_t R, int64_t D, int H) {
   Carver c(base);
   MlpWork w{};
-  for (int l = 0; l <= H; ++l) w.g[l] = c.take(size_t(R) * D);
+  for (int l = 0; l <= H; ++l) w.g[l] = c.take(pad_rows(size_t(R)) * D);
   w.wg = c.take_bytes(wgrad_work_bytes((int)D, 0));
   w.sw = c.take_bytes(small_wgrad_work_bytes((int)D));
   w.bytes = c.off;
