@@ -25,7 +25,7 @@ def _hipcc():
 
 
 def _digest():
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + os.environ.get("BSMS_CHAIN_FLAGS", "")).encode())
     for f in SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
@@ -44,6 +44,8 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         # no contraction: rowsum.hip rounds x*ew before the add like the reference; sim.hip keeps the fp64 normaliser roundings
         extra = ["-ffp-contract=off"] if src in ("rowsum.hip", "sim.hip") else []
+        if src == "chain.hip" and os.environ.get("BSMS_CHAIN_FLAGS"):   # A/B builds
+            extra += os.environ["BSMS_CHAIN_FLAGS"].split()
         cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

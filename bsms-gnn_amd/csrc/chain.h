@@ -42,10 +42,12 @@ constexpr int kChunkHdrFloats = 256;                     // 1 KB chunk header (b
 // A saved activation [rows, D] is followed by its ReLU sign bits, one bit per element packed per (row, lane group):
 // the backward chain masks gradients from 16 bytes per row instead of re-reading 4 D bytes.
 constexpr size_t mask_words_per_row(int64_t D) { return size_t(4) * (D <= 128 ? 1 : D / 128); }
-// Tensors the chain kernels write with their paired streaming stores are allocated for whole 64-row tiles: the
-// stores then need no per-lane bounds test (rows past R hold garbage nobody reads; the sign bits start after the padding).
-constexpr size_t pad_rows(size_t rows) { return (rows + kTileRows - 1) / kTileRows * kTileRows; }
-constexpr size_t act_floats(size_t rows, int64_t D) { return pad_rows(rows) * size_t(D) + rows * mask_words_per_row(D); }
+// Tensors the chain kernels write with their paired streaming stores are allocated for whole tiles (the largest tile:
+// kPadRows rows, the edge kernels with two row blocks per wave): the stores then need no per-lane bounds test (rows
+// past R hold garbage nobody reads; the sign bits start after the padding and are padded the same way).
+constexpr int kPadRows = 2 * kTileRows;
+constexpr size_t pad_rows(size_t rows) { return (rows + kPadRows - 1) / kPadRows * kPadRows; }
+constexpr size_t act_floats(size_t rows, int64_t D) { return pad_rows(rows) * (size_t(D) + mask_words_per_row(D)); }
 // row pitch (floats) of the saved fiber tensor: p + 1 values padded to one or two 16-byte pieces
 constexpr int fiber_ld(int64_t p) { return p + 1 <= 4 ? 4 : 8; }
 // floats in one weight pack of a D x D Linear (bf16 x 3 planes + headers)

@@ -776,6 +776,448 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   }  // tile loop
 }
 
+// store_pair_stream for the pipelined edge kernels: the tensor is non-null and padded (no tests), and the per-lane
+// part of both addresses is a 32-bit byte offset computed once per tile (offA / offB; the launcher checks 4 GB), so a
+// pair costs its DPP exchange and two stores with SGPR base + VGPR offset + immediate -- no 64-bit address arithmetic.
+struct PairOff { unsigned a, b; };
+template <int NB>
+__device__ __forceinline__ PairOff pair_offsets(int64_t row, int lane) {
+  constexpr int D = NB * 16;
+  const bool hi = (lane & 8) != 0;
+  const int64_t rowA = row - (lane & 8);
+  return PairOff{unsigned((rowA * D + 4 * (lane >> 4) + (hi ? 16 : 0)) * 4), unsigned(((rowA + 8) * D + 4 * (lane >> 4) + (hi ? 0 : 16)) * 4)};
+}
+template <int NB>
+__device__ __forceinline__ void store_pair_nt(const f32x4 (&v)[NB], float* base, PairOff off, int lane, int t) {
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  const bool hi = (lane & 8) != 0;
+  const i32x4 own = __builtin_bit_cast(i32x4, v[t + 1]);
+  i32x4 got;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) got[r] = __builtin_amdgcn_update_dpp(own[r], own[r], 0x128, 0xf, 0xf, false);
+  const f32x4 x = __builtin_bit_cast(f32x4, got);
+  const f32x4 dA = hi ? x : v[t], dB = hi ? v[t] : x;
+  char* b = reinterpret_cast<char*>(base) + 64 * t;   // uniform
+  __builtin_nontemporal_store(dA, reinterpret_cast<f32x4*>(b + off.a));
+  __builtin_nontemporal_store(dB, reinterpret_cast<f32x4*>(b + off.b));
+}
+
+// ------------------------------------------------------------- edge MLP chains, software-pipelined ----
+// The edge MLP (IN_EDGE / OUT_LN forward, G_EDGE_LN / F_NONE backward) is 45 % of the training step.  In k_chain_fwd /
+// k_chain_bwd every A-fragment pair is read from LDS right before its MFMAs (the 128-VGPR budget of two workgroups
+// per CU leaves no room to prefetch), so an in-order wave exposes one LDS round trip per 4 MFMAs and two waves per
+// SIMD hide only part of each other's stalls: the kernels run at ~55 % of their MFMA time (profiles/tile_timeline.py).
+// Here a wave owns RB row blocks of 16 rows: ONE fragment pair feeds 2 RB x {6, 4, 2} MFMAs, the next pair is in
+// flight while they run, 2 RB independent accumulator chains interleave (no dependent back-to-back MFMAs), and the
+// workgroup barrier + bias reads are paid once per RB x 64 rows.  RB = 2 at D = 128 (one workgroup per CU, 256-VGPR
+// budget), RB = 1 at D = 256 (the 32 + 32 blocks of one row block already fill the budget).
+// The arithmetic (order of the six partial products per accumulator) is exactly mfma_stage's: results are bit-identical.
+// The VALU work of a stage, cut into STEPS of 3-6 operations that are placed by hand between the MFMA pairs of the
+// chunk before the one that needs them (sched_barrier fences keep hipcc from regrouping them: left alone it emits the
+// split of a K block as one lump of ~45 VALU operations during which the matrix pipe drains, and its IGroupLP
+// pipelines (sched_group_barrier) either explode in compile time or silently skip some regions).  Per row block:
+//   P0..P3  streaming store of feature blocks 2c, 2c + 1 of the activation: DPP exchange (2 steps), select + store (2)
+//   S0..S11 exact three-way bf16 split of K block c + 1: per dword (two features) {hi, residual}, {mid, lo}, {3 packs}
+//   M0..M11 (last chunk of a saved activation instead of S) ReLU sign bits, then the store of the words
+struct Pieces { unsigned h[4], m[4], l[4]; };
+__device__ __forceinline__ float sub_nopk(float a, float b) {   // a - b that the SLP vectoriser cannot pack
+  float d;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ u32x4 vec4(const unsigned (&d)[4]) { return u32x4{d[0], d[1], d[2], d[3]}; }
+struct StepState {
+  __attribute__((ext_vector_type(2))) unsigned hh, m;
+  __attribute__((ext_vector_type(2))) float r1, l;
+  int got[4];
+};
+
+template <int NB, int RB, bool SAVE, bool MASK>
+__device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][NB], Pieces (&pc)[RB][2], StepState (&st)[RB],
+                                          unsigned (&mword)[RB][mask_words<NB>()], float* store_base, const PairOff (&off)[RB],
+                                          const unsigned (&moff)[RB], int64_t R, int lane) {
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  using u2 = __attribute__((ext_vector_type(2))) unsigned;
+  constexpr int D = NB * 16, W = mask_words<NB>(), NP = SAVE ? 4 : 0, PER = NP + 12;
+  const int rb = s / PER, q = s % PER;
+  if (rb >= RB) return;
+  const bool last = c + 1 == Ring<NB>::NCH;
+  if (q < NP) {   // ---- P steps
+    const f32x4& own = act[rb][2 * c + 1];
+    const bool hi = (lane & 8) != 0;
+    if (q < 2) {
+#pragma unroll
+      for (int r = 2 * q; r < 2 * q + 2; ++r) {
+        const int x = __float_as_int(own[r]);
+        st[rb].got[r] = __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);   // row_ror:8: partner's block 2c + 1
+      }
+    } else {
+      const f32x4& mine = act[rb][2 * c];
+      f32x4 d;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float g = __int_as_float(st[rb].got[r]);
+        d[r] = (q == 2) ? (hi ? g : mine[r]) : (hi ? mine[r] : g);
+      }
+      char* b = reinterpret_cast<char*>(store_base) + 128 * c;   // uniform; feature blocks 2c, 2c + 1
+      __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(b + (q == 2 ? off[rb].a : off[rb].b)));
+    }
+    return;
+  }
+  const int ss = q - NP;
+  if (!last) {    // ---- S steps: K block c + 1 -> pc[rb][(c + 1) & 1]
+    const int v = ss / 3, ph = ss % 3, kb2 = c + 1;
+    Pieces& o = pc[rb][kb2 & 1];
+    if (ph == 0) {
+      const f2 x = {act[rb][2 * kb2 + (v >> 1)][2 * (v & 1)], act[rb][2 * kb2 + (v >> 1)][2 * (v & 1) + 1]};
+      st[rb].hh = __builtin_bit_cast(u2, x) & 0xffff0000u;
+      // two scalar subtractions, not one v_pk_add_f32: beside MFMAs a packed fp32 operation costs ~13 cycles more than
+      // the two it replaces (MI355X_MICROARCH.md, price of fillers)
+      st[rb].r1[0] = sub_nopk(x[0], __uint_as_float(st[rb].hh[0]));
+      st[rb].r1[1] = sub_nopk(x[1], __uint_as_float(st[rb].hh[1]));
+    } else if (ph == 1) {
+      st[rb].m = __builtin_bit_cast(u2, st[rb].r1) & 0xffff0000u;
+      st[rb].l[0] = sub_nopk(st[rb].r1[0], __uint_as_float(st[rb].m[0]));
+      st[rb].l[1] = sub_nopk(st[rb].r1[1], __uint_as_float(st[rb].m[1]));
+    } else {
+      const u2 l = __builtin_bit_cast(u2, st[rb].l);
+      o.h[v] = __builtin_amdgcn_perm(st[rb].hh[1], st[rb].hh[0], 0x07060302u);
+      o.m[v] = __builtin_amdgcn_perm(st[rb].m[1], st[rb].m[0], 0x07060302u);
+      o.l[v] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+    }
+  } else if (SAVE && MASK) {   // ---- M steps
+    constexpr int EPS = (4 * NB + 11) / 12;
+#pragma unroll
+    for (int e = ss * EPS; e < (ss + 1) * EPS && e < 4 * NB; ++e) {
+      unsigned b;
+      asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(act[rb][e >> 2][e & 3])));   // post-ReLU value: positive iff non-zero bits
+      mword[rb][e >> 5] |= b << (e & 31);
+    }
+    if (ss == 11) {
+      unsigned* bits = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(store_base + pad_rows(R) * D) + moff[rb]);
+#pragma unroll
+      for (int w = 0; w < W; ++w) bits[w] = mword[rb][w];   // rows past R land in the padding (chain.h: act_floats)
+    }
+  }
+}
+
+template <int NB, int RB, bool SAVE, bool MASK, bool HDR>
+__device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, int& slot, int lane,
+                                         float* store_base, const PairOff (&off)[RB], const unsigned (&moff)[RB], int64_t R) {
+  using Rg = Ring<NB>;
+  constexpr int W = mask_words<NB>();
+  constexpr int NSLOT = (NB / 2) * 6 * RB;            // MFMA pairs per chunk
+  constexpr int NSTEP = RB * ((SAVE ? 4 : 0) + 12);   // VALU steps per chunk
+  static_assert(NSTEP <= NSLOT, "at most one step per MFMA pair");
+  Pieces pc[RB][2];                                   // split pieces of K blocks c (slot c & 1) and c + 1
+  StepState st[RB];
+  unsigned mword[RB][W];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    u32x4 h, m, l;
+    split_block<NB>(act[rb], 0, h, m, l);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { pc[rb][0].h[v] = h[v]; pc[rb][0].m[v] = m[v]; pc[rb][0].l[v] = l[v]; }
+#pragma unroll
+    for (int w = 0; w < W; ++w) mword[rb][w] = 0;
+  }
+#pragma unroll
+  for (int c = 0; c < Rg::NCH; ++c) {
+    lds_barrier();                                         // chunk has landed (and my reads of the last one are done)
+    const float4* cur = lds + slot * Rg::CH4;
+    if (++slot == Rg::NR) slot = 0;
+    const float4* body = cur + kChunkHdrFloats / 4 + lane;
+    float4 f0 = body[0], f1 = body[3 * 64];                // pair (t = 0, plane hi)
+    if (c == 0) {
+      if (HDR) {
+        const float* hdr = reinterpret_cast<const float*>(cur);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const float4 x = *reinterpret_cast<const float4*>(hdr + 16 * t + 4 * (lane >> 4));
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) acc[rb][t] = f32x4{x.x, x.y, x.z, x.w};
+        }
+      } else {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) zero_tile<NB>(acc[rb]);
+      }
+    }
+    const int cb = c & 1;
+    int islot = 0;   // MFMA pair within the chunk
+    // one MFMA pair (feature blocks t, t + 1 of row block rb, one plane combination), then the VALU step that rides with it
+    auto pair = [&](int t, int rb, const float4& a0, const float4& a1, const unsigned (&piece)[4]) {
+      acc[rb][t] = mma(a0, vec4(piece), acc[rb][t]);
+      acc[rb][t + 1] = mma(a1, vec4(piece), acc[rb][t + 1]);
+      const int s = (islot * NSTEP + NSLOT - 1) / NSLOT;          // the step whose place is this pair, if any
+      if (s < NSTEP && s * NSLOT / NSTEP == islot)
+        valu_step<NB, RB, SAVE, MASK>(s, c, act, pc, st, mword, store_base, off, moff, R, lane);
+      ++islot;
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NB; t += 2) {
+      float4 n0 = body[(t * 3 + 1) * 64], n1 = body[(t * 3 + 4) * 64];          // plane mid of (t, t + 1): one pair ahead
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].l);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].m);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h);
+      f0 = n0;
+      f1 = n1;
+      n0 = body[(t * 3 + 2) * 64];                                                // plane lo
+      n1 = body[(t * 3 + 5) * 64];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].m);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h);
+      f0 = n0;
+      f1 = n1;
+      if (t + 2 < NB) {                                                           // plane hi of the next block pair
+        n0 = body[((t + 2) * 3) * 64];
+        n1 = body[((t + 2) * 3 + 3) * 64];
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h);
+      f0 = n0;
+      f1 = n1;
+    }
+  }
+}
+
+// row of the [B, E] edge tensor -> (batch b, edge q) without the 64-bit division hipcc would emit (~100 instructions
+// per lane and tile): float reciprocal estimate, corrected by at most one step either way (rows < 2^31, launcher).
+struct EdgeRef { int b, q; };
+__device__ __forceinline__ EdgeRef edge_ref(unsigned row, unsigned E, float rcpE) {
+  int b = int(float(row) * rcpE);
+  int q = int(row) - b * int(E);
+  if (q < 0) { q += int(E); --b; }
+  if (q >= int(E)) { q -= int(E); ++b; }
+  return EdgeRef{b, q};
+}
+
+template <int NB, int RB>
+struct EdgeTile {
+  static constexpr int rows = kTileRows * RB;
+  static constexpr int waves_per_eu = (NB * RB <= 8) ? 4 : 2;   // VGPR budget 128 / 256
+  static constexpr int resident = (NB * RB <= 8) ? 2 : 1;       // workgroups per CU (see resident_per_cu)
+};
+
+template <int NB, int RB, bool SAVE>
+__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(EdgeTile<NB, RB>::waves_per_eu)))
+void k_edge_fwd(ChainFwdArgs a) {
+  constexpr int D = NB * 16;
+  extern __shared__ __attribute__((aligned(16))) float4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
+  if (wave == kComputeWaves) {  // loader wave (uniform branch)
+    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles, a.w0t);
+    return;
+  }
+  const float rcpE = 1.f / float(a.E);
+  // plan-order endpoints of this lane's rows in a tile; fetched one tile ahead (two registers per row block), so a tile
+  // starts with its row gathers instead of a dependent index round trip
+  auto fetch_endpoints = [&](int tile, int (&i)[RB], int (&j)[RB], int (&b)[RB]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int64_t r = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
+      const EdgeRef e = edge_ref(unsigned(r < a.R ? r : 0), unsigned(a.E), rcpE);   // a lane past the end reads row 0
+      i[rb] = a.src[e.q];
+      j[rb] = a.dst[e.q];
+      b[rb] = e.b;
+    }
+  };
+  int ni[RB], nj[RB], nbat[RB];
+  fetch_endpoints(blockIdx.x, ni, nj, nbat);
+  lds_barrier();
+  const float* w0t = ring_side<NB>(lds);   // fiber weights (LDS side table, see k_chain_fwd)
+  int slot = 0;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int64_t row[RB];
+    PairOff off[RB];
+    unsigned moff[RB];   // byte offset of this lane's sign-bit words
+    f32x4 act[RB][NB], acc[RB][NB];
+    float pi[RB][7], pj[RB][7];
+#ifdef BSMS_EXPERIMENTS
+    int stamp_i = 0;
+    auto stamp = [&]() { if (a.timing && tid == 0 && stamp_i < 16) a.timing[int64_t(tile) * 16 + stamp_i++] = __builtin_amdgcn_s_memtime(); };
+#else
+    auto stamp = [] {};
+#endif
+    stamp();
+    // ---- input stage: relu(Ps[src] + Pd[dst] + Wf . [pos_i - pos_j, |pos_i - pos_j|])   (ops/basic.py:70-92)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      row[rb] = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
+      off[rb] = pair_offsets<NB>(row[rb], lane);
+      moff[rb] = unsigned((row[rb] * (4 * mask_words<NB>()) + lg * mask_words<NB>()) * 4);
+      const int i = ni[rb], j = nj[rb], b = nbat[rb];
+      load_rows<NB>(act[rb], a.Ps + (int64_t(b) * a.N + i) * D, lg);
+      load_rows<NB>(acc[rb], a.Pd + (int64_t(b) * a.N + j) * D, lg);
+      const float* pb = a.pos + b * a.pos_bstride;
+      if (a.p == 2) {   // uniform; the common widths load whole points
+        const float2 xi = *reinterpret_cast<const float2*>(pb + int64_t(i) * 2), xj = *reinterpret_cast<const float2*>(pb + int64_t(j) * 2);
+        pi[rb][0] = xi.x; pi[rb][1] = xi.y; pj[rb][0] = xj.x; pj[rb][1] = xj.y;
+#pragma unroll
+        for (int c = 2; c < 7; ++c) pi[rb][c] = pj[rb][c] = 0.f;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          const int cc = c < a.p ? c : 0;   // uniform clamp: the loads stay unconditional
+          pi[rb][c] = pb[int64_t(i) * a.p + cc];
+          pj[rb][c] = pb[int64_t(j) * a.p + cc];
+        }
+      }
+    }
+    if (tile + int(gridDim.x) < a.ntiles) fetch_endpoints(tile + gridDim.x, ni, nj, nbat);   // uniform; lands under the stages
+    __builtin_amdgcn_sched_barrier(0);   // all gathers of the tile are in flight before the first use
+    stamp();
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+      for (int t = 0; t < NB; ++t) act[rb][t] += acc[rb][t];
+      float n2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 7; ++c)
+        if (c < a.p) {
+          const float rel = pi[rb][c] - pj[rb][c];
+          n2 = fmaf(rel, rel, n2);
+          axpy_features<NB>(act[rb], w0t + c * D, rel, lg);
+        }
+      const float nrm = sqrtf(n2);
+      axpy_features<NB>(act[rb], w0t + a.p * D, nrm, lg);
+      relu_into<NB>(act[rb], act[rb]);
+      if (SAVE && a.fiber_out && row[rb] < a.R && lg == 0) {   // one lane per row keeps the fiber for the backward
+        float f[8];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) f[c] = c < a.p ? pi[rb][c] - pj[rb][c] : (c == a.p ? nrm : 0.f);
+        f[7] = a.p == 7 ? nrm : 0.f;
+        const int ld = fiber_ld(a.p);
+        float4* dst = reinterpret_cast<float4*>(a.fiber_out + row[rb] * ld);
+        dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+        if (ld == 8) dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+      }
+    }
+    // ---- MFMA stages; the activation entering a stage is stored (values + sign bits) from inside that stage
+    float* pending = a.store_in;   // uniform; non-null when SAVE (launcher)
+    stamp();
+    for (int l = 0; l < a.nstage; ++l) {
+      stage_rb<NB, RB, SAVE, true, true>(acc, act, lds, slot, lane, pending, off, moff, a.R);   // acc = bias + W act
+      stamp();
+      if (l + 1 < a.nstage) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) relu_into<NB>(act[rb], acc[rb]);
+        pending = a.store[l];
+      }
+    }
+    // ---- LayerNorm(elementwise_affine=False), eps 1e-5  (ops/basic.py:18)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const float mean = row_sum<NB>(acc[rb]) * (1.f / D);
+      float ss = 0.f;
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[rb][t][r] -= mean;
+          ss = fmaf(acc[rb][t][r], acc[rb][t][r], ss);
+        }
+      ss = group_sum(ss);
+      const float rstd = 1.f / sqrtf(ss * (1.f / D) + 1e-5f);
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rb][t][r] *= rstd;
+      const int64_t roff = row[rb] < a.R ? row[rb] * D : -1;
+      store_rows<NB, false>(acc[rb], a.yln, roff, lg);
+      if (a.rstd && roff >= 0 && lg == 0) a.rstd[row[rb]] = rstd;
+      store_rows<NB, false>(acc[rb], a.y, roff, lg, a.out_mode);
+    }
+    stamp();
+  }
+}
+
+template <int NB, int RB>
+__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(EdgeTile<NB, RB>::waves_per_eu)))
+void k_edge_bwd(ChainBwdArgs a) {
+  constexpr int D = NB * 16, W = mask_words<NB>();
+  extern __shared__ __attribute__((aligned(16))) float4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
+  if (wave == kComputeWaves) {  // loader wave (uniform branch)
+    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles);
+    return;
+  }
+  const float rcpE = 1.f / float(a.E);
+  auto fetch_targets = [&](int tile, int64_t (&node)[RB]) {   // node row (b * N + dst) of this lane's rows, one tile ahead
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int64_t r = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
+      const EdgeRef e = edge_ref(unsigned(r < a.R ? r : 0), unsigned(a.E), rcpE);
+      node[rb] = int64_t(e.b) * a.N + a.dst[e.q];
+    }
+  };
+  int64_t nnode[RB];
+  fetch_targets(blockIdx.x, nnode);
+  int slot = 0;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int64_t row[RB], rowc[RB];
+    PairOff off[RB];
+    unsigned moff[RB];
+    f32x4 g[RB][NB], acc[RB][NB];
+    float rs[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {   // autograd of scatter_sum: gather the node gradient by target; y, rstd of the row
+      row[rb] = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
+      rowc[rb] = row[rb] < a.R ? row[rb] : 0;
+      off[rb] = pair_offsets<NB>(row[rb], lane);
+      moff[rb] = 0;
+      load_rows<NB>(g[rb], a.dy + nnode[rb] * D, lg);
+      load_rows<NB>(acc[rb], a.yln + rowc[rb] * D, lg);
+      rs[rb] = a.rstd[rowc[rb]];
+    }
+    if (tile + int(gridDim.x) < a.ntiles) fetch_targets(tile + gridDim.x, nnode);   // uniform; lands under the stages
+    __builtin_amdgcn_sched_barrier(0);   // all loads in flight before the first use
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {   // LayerNorm backward (no affine): dz = rstd * (dy - mean(dy) - y * mean(dy * y))
+      const float m1 = row_sum<NB>(g[rb]) * (1.f / D);
+      float s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s2 = fmaf(g[rb][t][r], acc[rb][t][r], s2);
+      s2 = group_sum(s2);
+      const float m2 = s2 * (1.f / D);
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[rb][t][r] = rs[rb] * (g[rb][t][r] - m1 - acc[rb][t][r] * m2);
+    }
+    float* pending = a.gstore[0];   // uniform, non-null (launcher): the gradient entering a stage is stored inside it
+    for (int k = 0; k < a.nstage; ++k) {
+      unsigned mbits[RB][W];   // ReLU sign bits of the activation that masks this stage's output, loaded ahead of the stage
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+          mbits[rb][w] = reinterpret_cast<const unsigned*>(a.mask[k] + pad_rows(a.R) * D)[rowc[rb] * (4 * W) + lg * W + w];
+      stage_rb<NB, RB, true, false, false>(acc, g, lds, slot, lane, pending, off, moff, a.R);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {   // bit -> all-ones / zero mask (one v_bfe_i32), then one and
+            const int keep = __builtin_amdgcn_sbfe((int)mbits[rb][(4 * t + r) >> 5], (4 * t + r) & 31, 1);
+            g[rb][t][r] = __uint_as_float(__float_as_uint(acc[rb][t][r]) & (unsigned)keep);
+          }
+      pending = a.gstore[k + 1];
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)   // gE[0]: read next by the scatter kernel, plain stores (stay in L2 / the memory-side cache)
+      store_rows<NB, false>(g[rb], pending, row[rb] < a.R ? row[rb] * D : -1, lg);
+  }
+}
+
 // Workgroups of 5 waves the chip keeps resident per CU at each width.  NOT the occupancy API's answer: the SPI
 // accounts a 5-wave workgroup like an 8-wave one (census: 320 threads x 120 VGPRs -> 2 per CU where the API says 3;
 // profiles/census).  A grid larger than the residency would only queue, a smaller one idles slots.
@@ -794,6 +1236,87 @@ unsigned persistent_grid(int64_t ntiles) {
   return (unsigned)std::min<int64_t>(ntiles, int64_t(cus) * resident_per_cu<NB>());
 }
 
+
+inline int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// experiment builds (same-box A/B, profiles/edge_prof.sh): BSMS_EDGE_RB = 0 keeps the edge MLP on k_chain_fwd / k_chain_bwd,
+// 1 / 2 force the number of row blocks per wave
+inline int edge_rb_mode() {
+#ifdef BSMS_EXPERIMENTS
+  static const int m = [] { const char* e = getenv("BSMS_EDGE_RB"); return e ? atoi(e) : -1; }();
+  return m;
+#else
+  return -1;
+#endif
+}
+
+template <int NB, int RB, bool SAVE>
+int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes);
+  a.ntiles = (int)ceil_div(a.R, EdgeTile<NB, RB>::rows);
+  const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
+  hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE>), dim3(grid), dim3(kChainThreads), Ring<NB>::lds_bytes, s, a);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
+
+// the software-pipelined edge kernels take the production configuration only; anything else stays on k_chain_fwd
+template <int NB>
+bool launch_edge_fwd(ChainFwdArgs& a, hipStream_t s, int& rc) {
+  if (a.bf16 || a.nstage < 1 || a.store_mode != 1 || a.resid || a.resid2 || edge_rb_mode() == 0) return false;
+  if (pad_rows(size_t(a.R)) * size_t(NB * 16) * 4 >= (size_t(1) << 32)) return false;   // 32-bit store offsets
+  const bool save = a.store_in != nullptr;
+  for (int l = 0; l + 1 < a.nstage; ++l)
+    if ((a.store[l] != nullptr) != save) return false;
+  constexpr int RBIG = NB == 8 ? 2 : 1;
+  // Measured per level (profiles/r02_edge_levels.md): with several tiles per workgroup two workgroups per CU of one row
+  // block per wave win the forward (the random row gathers of one hide under the other's MFMA stages); a launch that
+  // fits one round of workgroups is faster with two row blocks per wave, and so is the whole backward (its loads are
+  // sequential or local).  Below half a round of 128-row tiles the narrow tile keeps more CUs busy.
+  const int64_t cus = device_cus();
+  bool big = RBIG == 2 && a.R >= cus * EdgeTile<NB, RBIG>::rows / 2 && ceil_div(a.R, EdgeTile<NB, 1>::rows) <= cus * EdgeTile<NB, 1>::resident;
+  if (edge_rb_mode() > 0) big = RBIG == 2 && edge_rb_mode() == 2;
+  if (big) rc = save ? launch_edge_fwd_t<NB, RBIG, true>(a, s) : launch_edge_fwd_t<NB, RBIG, false>(a, s);
+  else rc = save ? launch_edge_fwd_t<NB, 1, true>(a, s) : launch_edge_fwd_t<NB, 1, false>(a, s);
+  return true;
+}
+
+template <int NB, int RB>
+int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes);
+  a.ntiles = (int)ceil_div(a.R, EdgeTile<NB, RB>::rows);
+  const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
+  hipLaunchKernelGGL((k_edge_bwd<NB, RB>), dim3(grid), dim3(kChainThreads), Ring<NB>::lds_bytes, s, a);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
+
+template <int NB>
+bool launch_edge_bwd(ChainBwdArgs& a, hipStream_t s, int& rc) {
+  if (a.bf16 || a.nstage < 1 || a.store_mode != 1 || edge_rb_mode() == 0) return false;
+  if (pad_rows(size_t(a.R)) * size_t(NB * 16) * 4 >= (size_t(1) << 32)) return false;   // 32-bit store offsets
+  for (int k = 0; k <= a.nstage; ++k)
+    if (!a.gstore[k] || (k < a.nstage && !a.mask[k])) return false;
+  constexpr int RBIG = NB == 8 ? 2 : 1;
+  bool big = RBIG == 2 && a.R >= int64_t(device_cus()) * EdgeTile<NB, RBIG>::rows / 2;   // see launch_edge_fwd
+  if (edge_rb_mode() > 0) big = RBIG == 2 && edge_rb_mode() == 2;
+  rc = big ? launch_edge_bwd_t<NB, RBIG>(a, s) : launch_edge_bwd_t<NB, 1>(a, s);
+  return true;
+}
+
 template <int NB, int IN, int OUT>
 int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   ChainFwdArgs a = a0;
@@ -806,6 +1329,10 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve %zu bytes of LDS", lds);
+  if constexpr ((NB == 8 || NB == 16) && IN == IN_EDGE && OUT == OUT_LN) {
+    int rc = BSMS_OK;
+    if (launch_edge_fwd<NB>(a, s, rc)) return rc;
+  }
   a.ntiles = (int)ceil_div(a.R, kTileRows);
   bool launched = false;
   if constexpr (NB == 8 && IN == IN_EDGE) {   // the only instantiation with stamps
@@ -862,6 +1389,9 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", lds);
   a.ntiles = (int)ceil_div(a.R, kTileRows);
   if constexpr ((NB == 8 || NB == 16) && GIN == G_EDGE_LN && FIRST == F_NONE) {
+    int rc = BSMS_OK;
+    if (launch_edge_bwd<NB>(a, s, rc)) return rc;
+    a.ntiles = (int)ceil_div(a.R, kTileRows);
     if (a.bf16) {
       static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);

@@ -75,7 +75,7 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
   Carver c(base);
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
-  const size_t edge_act = bf ? pad_rows(re) * size_t(D) / 2 + re * mask_words_per_row(D) : act_floats(re, D);
+  const size_t edge_act = bf ? pad_rows(re) * (size_t(D) / 2 + mask_words_per_row(D)) : act_floats(re, D);
   if (training)
     for (int l = 0; l < H; ++l) s.e_act[l] = c.take(edge_act);
   s.e_y = c.take(bf ? re * D / 2 : re * D);
