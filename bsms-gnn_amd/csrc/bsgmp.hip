@@ -220,6 +220,24 @@ extern "C" int bsms_bsgmp_bwd_p(const bsms_plan_t* const* plans, const float* co
                                 const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                                 const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
                                 int precision, bsms_stream_t stream) {
+  return bsms_bsgmp_bwd_ex(plans, ew, L, h, pos, grad_out, B, D, p, pos_batch_stride, hidden, params, saved, work, grad_h, grads,
+                           precision, 0, stream);
+}
+
+extern "C" int bsms_side_lanes_join(bsms_stream_t stream) {
+  SideLane *lane0 = nullptr, *lane1 = nullptr;
+  int rc;
+  if ((rc = side_lane(&lane0, 0)) || (rc = side_lane(&lane1, 1))) return rc;
+  hipStream_t st = as_stream(stream);
+  for (int slot = 0; slot < 2; ++slot)   // a slot nobody marked is an event that was never recorded: the wait is a no-op
+    if ((rc = side_wait_mark(lane0, slot, st)) || (rc = side_wait_mark(lane1, slot, st))) return rc;
+  return BSMS_OK;
+}
+
+extern "C" int bsms_bsgmp_bwd_ex(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                                 const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                                 const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
+                                 int precision, int flags, bsms_stream_t stream) {
   Shape s;
   int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_bwd");
   if (rc) return rc;
@@ -282,7 +300,9 @@ extern "C" int bsms_bsgmp_bwd_p(const bsms_plan_t* const* plans, const float* co
     if ((rc = run_block(i, hin_l[i], gs, i, gx))) return rc;
     gl = gx;
   }
-  // every weight gradient has to be complete when the call returns
+  // every weight gradient has to be complete when the call returns -- unless the caller has more work for this stream
+  // that touches neither `work` nor `grads` and joins the lanes itself afterwards (BSMS_BWD_DEFER_JOIN)
+  if (flags & BSMS_BWD_DEFER_JOIN) return BSMS_OK;
   for (int slot = 0; slot < 2; ++slot)
     if (marked[slot] && ((rc = side_wait_mark(lane0, slot, st)) || (rc = side_wait_mark(lane1, slot, st)))) return rc;
   return BSMS_OK;

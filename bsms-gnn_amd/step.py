@@ -88,6 +88,7 @@ class FusedStep:
                  prec=m.process.precision,
                  work=u8(max(L.bsms_mlp_work_bytes(R, C + 1, D, D, H), L.bsms_mlp_work_bytes(R, D, D, C, H),
                              L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, H), L.bsms_sim_work_bytes(R))),
+                 work_enc=u8(L.bsms_mlp_work_bytes(R, C + 1, D, D, H)),   # the encoder's backward overlaps the U-Net's last weight gradients
                  in_static=None)
         self._shape_key, self._buf, self._graphs = key, b, None
         return b
@@ -126,11 +127,14 @@ class FusedStep:
         ck(L.bsms_mlp_bwd(b["h1"].data_ptr(), b["g_np"].data_ptr(), R, D, D, C, H, 0, t["dec"][0][0], b["s_dec"].data_ptr(),
                           work.data_ptr(), b["gh1"].data_ptr(), t["dec"][1][0], s), "bsms_mlp_bwd(decode)")
         ewp, keep = _abi.ptr_array([e.data_ptr() for e in ews])
-        ck(L.bsms_bsgmp_bwd_p(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), b["gh1"].data_ptr(), B, D, p, N * p, H,
-                              t["proc"][0][0], b["s_proc"].data_ptr(), work.data_ptr(), b["gh0"].data_ptr(), t["proc"][1][0],
-                              PRECISIONS[b["prec"]], s), "bsms_bsgmp_bwd")
+        # BSMS_BWD_DEFER_JOIN: the weight gradients of the last (level-0) block are still running on the engine's side
+        # streams (~0.2 ms on half the chip) while the encoder's backward -- own scratch, own gradient slots -- runs here
+        ck(L.bsms_bsgmp_bwd_ex(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), b["gh1"].data_ptr(), B, D, p, N * p, H,
+                               t["proc"][0][0], b["s_proc"].data_ptr(), work.data_ptr(), b["gh0"].data_ptr(), t["proc"][1][0],
+                               PRECISIONS[b["prec"]], 1, s), "bsms_bsgmp_bwd")
         ck(L.bsms_mlp_bwd(b["norm_in"].data_ptr(), b["gh0"].data_ptr(), R, C + 1, D, D, H, 1, t["enc"][0][0], b["s_enc"].data_ptr(),
-                          work.data_ptr(), None, t["enc"][1][0], s), "bsms_mlp_bwd(encode)")
+                          b["work_enc"].data_ptr(), None, t["enc"][1][0], s), "bsms_mlp_bwd(encode)")
+        ck(L.bsms_side_lanes_join(s), "bsms_side_lanes_join")
 
     # ------------------------------------------------------------------------------------------------ the step
     def __call__(self, data, consistent=True):

@@ -191,6 +191,16 @@ int bsms_bsgmp_bwd(const bsms_plan_t* const* plans, const float* const* ew, int 
                    const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                    const float* const* params, const void* saved, void* work, float* grad_h,
                    float* const* grads, bsms_stream_t stream);
+/* bsms_bsgmp_bwd_p with `flags`.  BSMS_BWD_DEFER_JOIN: the weight gradients of the last blocks may still be running on
+ * the engine's internal side streams when the call returns; `grad_h` is complete in stream order.  The caller may enqueue
+ * work that touches neither `work` nor `grads` (the fused training step runs the encoder's backward there, with its own
+ * scratch) and MUST call bsms_side_lanes_join(stream) before anything reads `grads`, reuses `work`, or the step ends. */
+enum { BSMS_BWD_DEFER_JOIN = 1 };
+int bsms_bsgmp_bwd_ex(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                      const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                      const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
+                      int precision, int flags, bsms_stream_t stream);
+int bsms_side_lanes_join(bsms_stream_t stream);
 
 
 /* ---------------------------------------------------------------- A10-A12: model glue + loss -
