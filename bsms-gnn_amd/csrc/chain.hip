@@ -777,8 +777,8 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
 }
 
 // store_pair_stream for the pipelined edge kernels: the tensor is non-null and padded (no tests), and the per-lane
-// part of both addresses is a 32-bit byte offset computed once per tile (offA / offB; the launcher checks 4 GB), so a
-// pair costs its DPP exchange and two stores with SGPR base + VGPR offset + immediate -- no 64-bit address arithmetic.
+// part of both addresses is a 32-bit byte offset WITHIN THE TILE, computed once per kernel (the tile's base is uniform
+// 64-bit scalar arithmetic), so a pair costs its DPP exchange and two stores with SGPR base + VGPR offset + immediate.
 struct PairOff { unsigned a, b; };
 template <int NB>
 __device__ __forceinline__ PairOff pair_offsets(int64_t row, int lane) {
@@ -834,11 +834,11 @@ struct StepState {
 
 template <int NB, int RB, bool SAVE, bool MASK>
 __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][NB], Pieces (&pc)[RB][2], StepState (&st)[RB],
-                                          unsigned (&mword)[RB][mask_words<NB>()], float* store_base, const PairOff (&off)[RB],
-                                          const unsigned (&moff)[RB], int64_t R, int lane) {
+                                          unsigned (&mword)[RB][mask_words<NB>()], float* store_base, unsigned* bits_base,
+                                          const PairOff (&off)[RB], const unsigned (&moff)[RB], int lane) {
   using f2 = __attribute__((ext_vector_type(2))) float;
   using u2 = __attribute__((ext_vector_type(2))) unsigned;
-  constexpr int D = NB * 16, W = mask_words<NB>(), NP = SAVE ? 4 : 0, PER = NP + 12;
+  constexpr int W = mask_words<NB>(), NP = SAVE ? 4 : 0, PER = NP + 12;
   const int rb = s / PER, q = s % PER;
   if (rb >= RB) return;
   const bool last = c + 1 == Ring<NB>::NCH;
@@ -894,7 +894,7 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
       mword[rb][e >> 5] |= b << (e & 31);
     }
     if (ss == 11) {
-      unsigned* bits = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(store_base + pad_rows(R) * D) + moff[rb]);
+      unsigned* bits = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(bits_base) + moff[rb]);
 #pragma unroll
       for (int w = 0; w < W; ++w) bits[w] = mword[rb][w];   // rows past R land in the padding (chain.h: act_floats)
     }
@@ -903,7 +903,7 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
 
 template <int NB, int RB, bool SAVE, bool MASK, bool HDR>
 __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, int& slot, int lane,
-                                         float* store_base, const PairOff (&off)[RB], const unsigned (&moff)[RB], int64_t R) {
+                                         float* store_base, unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB]) {
   using Rg = Ring<NB>;
   constexpr int W = mask_words<NB>();
   constexpr int NSLOT = (NB / 2) * 6 * RB;            // MFMA pairs per chunk
@@ -950,7 +950,7 @@ __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act
       acc[rb][t + 1] = mma(a1, vec4(piece), acc[rb][t + 1]);
       const int s = (islot * NSTEP + NSLOT - 1) / NSLOT;          // the step whose place is this pair, if any
       if (s < NSTEP && s * NSLOT / NSTEP == islot)
-        valu_step<NB, RB, SAVE, MASK>(s, c, act, pc, st, mword, store_base, off, moff, R, lane);
+        valu_step<NB, RB, SAVE, MASK>(s, c, act, pc, st, mword, store_base, bits_base, off, moff, lane);
       ++islot;
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -1049,8 +1049,8 @@ void k_edge_fwd(ChainFwdArgs a) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       row[rb] = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
-      off[rb] = pair_offsets<NB>(row[rb], lane);
-      moff[rb] = unsigned((row[rb] * (4 * mask_words<NB>()) + lg * mask_words<NB>()) * 4);
+      off[rb] = pair_offsets<NB>(wave * (16 * RB) + rb * 16 + (lane & 15), lane);                         // within the tile
+      moff[rb] = unsigned(((wave * (16 * RB) + rb * 16 + (lane & 15)) * (4 * mask_words<NB>()) + lg * mask_words<NB>()) * 4);
       const int i = ni[rb], j = nj[rb], b = nbat[rb];
       load_rows<NB>(act[rb], a.Ps + (int64_t(b) * a.N + i) * D, lg);
       load_rows<NB>(acc[rb], a.Pd + (int64_t(b) * a.N + j) * D, lg);
@@ -1102,7 +1102,9 @@ void k_edge_fwd(ChainFwdArgs a) {
     float* pending = a.store_in;   // uniform; non-null when SAVE (launcher)
     stamp();
     for (int l = 0; l < a.nstage; ++l) {
-      stage_rb<NB, RB, SAVE, true, true>(acc, act, lds, slot, lane, pending, off, moff, a.R);   // acc = bias + W act
+      float* st_tile = SAVE ? pending + int64_t(tile) * (EdgeTile<NB, RB>::rows * D) : nullptr;   // uniform
+      unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (EdgeTile<NB, RB>::rows * 4 * mask_words<NB>()) : nullptr;
+      stage_rb<NB, RB, SAVE, true, true>(acc, act, lds, slot, lane, st_tile, bits_tile, off, moff);   // acc = bias + W act
       stamp();
       if (l + 1 < a.nstage) {
 #pragma unroll
@@ -1169,7 +1171,7 @@ void k_edge_bwd(ChainBwdArgs a) {
     for (int rb = 0; rb < RB; ++rb) {   // autograd of scatter_sum: gather the node gradient by target; y, rstd of the row
       row[rb] = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
       rowc[rb] = row[rb] < a.R ? row[rb] : 0;
-      off[rb] = pair_offsets<NB>(row[rb], lane);
+      off[rb] = pair_offsets<NB>(wave * (16 * RB) + rb * 16 + (lane & 15), lane);   // within the tile
       moff[rb] = 0;
       load_rows<NB>(g[rb], a.dy + nnode[rb] * D, lg);
       load_rows<NB>(acc[rb], a.yln + rowc[rb] * D, lg);
@@ -1200,7 +1202,7 @@ void k_edge_bwd(ChainBwdArgs a) {
 #pragma unroll
         for (int w = 0; w < W; ++w)
           mbits[rb][w] = reinterpret_cast<const unsigned*>(a.mask[k] + pad_rows(a.R) * D)[rowc[rb] * (4 * W) + lg * W + w];
-      stage_rb<NB, RB, true, false, false>(acc, g, lds, slot, lane, pending, off, moff, a.R);
+      stage_rb<NB, RB, true, false, false>(acc, g, lds, slot, lane, pending + int64_t(tile) * (EdgeTile<NB, RB>::rows * D), nullptr, off, moff);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -1274,8 +1276,7 @@ int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
 // the software-pipelined edge kernels take the production configuration only; anything else stays on k_chain_fwd
 template <int NB>
 bool launch_edge_fwd(ChainFwdArgs& a, hipStream_t s, int& rc) {
-  if (a.bf16 || a.nstage < 1 || a.store_mode != 1 || a.resid || a.resid2 || edge_rb_mode() == 0) return false;
-  if (pad_rows(size_t(a.R)) * size_t(NB * 16) * 4 >= (size_t(1) << 32)) return false;   // 32-bit store offsets
+  if (a.bf16 || a.nstage < 1 || a.store_mode != 1 || a.resid || a.resid2 || edge_rb_mode() == 0 || a.R >= (int64_t(1) << 31)) return false;
   const bool save = a.store_in != nullptr;
   for (int l = 0; l + 1 < a.nstage; ++l)
     if ((a.store[l] != nullptr) != save) return false;
@@ -1306,8 +1307,7 @@ int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
 
 template <int NB>
 bool launch_edge_bwd(ChainBwdArgs& a, hipStream_t s, int& rc) {
-  if (a.bf16 || a.nstage < 1 || a.store_mode != 1 || edge_rb_mode() == 0) return false;
-  if (pad_rows(size_t(a.R)) * size_t(NB * 16) * 4 >= (size_t(1) << 32)) return false;   // 32-bit store offsets
+  if (a.bf16 || a.nstage < 1 || a.store_mode != 1 || edge_rb_mode() == 0 || a.R >= (int64_t(1) << 31)) return false;
   for (int k = 0; k <= a.nstage; ++k)
     if (!a.gstore[k] || (k < a.nstage && !a.mask[k])) return false;
   constexpr int RBIG = NB == 8 ? 2 : 1;

@@ -51,8 +51,10 @@ def main():
     wg = ["decoder"] + [f"L{l} {w}" for l in unet for w in ("D x D layers", "projections")] + ["encoder"]
     families = {"k_rowsum_v4<32, false, false": ("edge aggregation (unweighted plan-order row sum)", [f"L{l}" for l in unet]),
                 "k_rowsum_pair": ("both scatters of gE[0] (by source + by target) in one launch", [f"L{l}" for l in unet]),
-                "k_chain_fwd<8, 3, 0": ("edge MLP forward chain (IN_EDGE, OUT_LN)", [f"L{l}" for l in unet]),
-                "k_chain_bwd<8, 1, 0": ("edge MLP backward chain (G_EDGE_LN)", [f"L{l}" for l in unet]),
+                "k_edge_fwd<8": ("edge MLP forward chain (pipelined kernel; <8, RB, save>: RB row blocks per wave)", [f"L{l}" for l in unet]),
+                "k_edge_bwd<8": ("edge MLP backward chain (pipelined kernel)", [f"L{l}" for l in unet]),
+                "k_chain_fwd<8, 3, 0": ("edge MLP forward chain (IN_EDGE, OUT_LN; builds before the pipelined kernels)", [f"L{l}" for l in unet]),
+                "k_chain_bwd<8, 1, 0": ("edge MLP backward chain (G_EDGE_LN; builds before the pipelined kernels)", [f"L{l}" for l in unet]),
                 "k_chain_fwd<8, 1, 0": ("node MLP forward chain (IN_ROWS2, OUT_LN)", [f"L{l}" for l in unet]),
                 "k_chain_bwd<8, 0, 2": ("node MLP backward chain", [f"L{l}" for l in unet]),
                 "k_wgrad<": ("batched split-K weight gradients", wg)}
@@ -74,7 +76,7 @@ def main():
         if key.startswith("k_rowsum_pair"):
             w = 2 * B * e * D * S + 2 * B * n * D * S
             return f"{w / 1e6:.1f} MB -> {w / t / 1e12:.2f} TB/s = {w / t / HBM_PEAK:.2f} of HBM peak"
-        if key.startswith("k_chain_fwd<8, 3") or key.startswith("k_chain_bwd<8, 1"):
+        if key.startswith("k_chain_fwd<8, 3") or key.startswith("k_chain_bwd<8, 1") or key.startswith("k_edge_"):
             fl = 2 * B * e * 3 * D * D
             by = B * e * D * S * (4 if "fwd" in key else 5)   # fwd: 3 saved activations + messages; bwd: 4 layer gradients + y
             return (f"{fl / 1e9:.1f} GFLOP -> {fl / t / 1e12:.0f} TF/s = {fl / t / SPLIT_PEAK:.2f} of split-bf16 peak; "
