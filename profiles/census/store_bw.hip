@@ -19,8 +19,12 @@ __global__ __launch_bounds__(256) void k_store(float* out, long rows) {
       else if (PATTERN == 1) p = reinterpret_cast<f32x4*>(out + (row0 + (lane & 15)) * 128 + 16 * t + 4 * (lane >> 4));   // chain layout
       else if (PATTERN == 2)   // 8 rows x 128 B per instruction: lane (r = lane & 7, seg = lane >> 3), t -> (row half, 128-B column)
         p = reinterpret_cast<f32x4*>(out + (row0 + 8 * (t & 1) + (lane & 7)) * 128 + 32 * (t >> 1) + 4 * (lane >> 3));
-      else                     // 4 rows x 256 B per instruction
+      else if (PATTERN == 3)   // 4 rows x 256 B per instruction
         p = reinterpret_cast<f32x4*>(out + (row0 + 4 * (t & 3) + (lane & 3)) * 128 + 64 * (t >> 2) + 4 * (lane >> 2));
+      else {                   // 32x32 MFMA accumulator layout: lane (row = lane & 31, h = lane >> 5), 32-byte pieces; two passes of 8
+        const long r32 = tile * 64 + (wave >> 1) * 32 + (lane & 31);
+        p = reinterpret_cast<f32x4*>(out + r32 * 128 + 8 * (t + 8 * (wave & 1)) + 4 * (lane >> 5));
+      }
       if (NT) __builtin_nontemporal_store(v, p); else *p = v;
     }
   }
@@ -74,6 +78,8 @@ int main() {
   run<2, true>(d, rows, "8 rows x 128 B pieces, nt");
   run<3, false>(d, rows, "4 rows x 256 B pieces, plain");
   run<3, true>(d, rows, "4 rows x 256 B pieces, nt");
+  run<4, false>(d, rows, "32x32 layout (32 B pieces), plain");
+  run<4, true>(d, rows, "32x32 layout (32 B pieces), nt");
   runl<0>(d, rows, "LOAD lane-linear");
   runl<1>(d, rows, "LOAD chain layout (64 B pieces)");
   runl<2>(d, rows, "LOAD 8 rows x 128 B pieces");

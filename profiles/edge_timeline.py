@@ -26,8 +26,12 @@ for lvl in (0, 3):
         gmp(x, g0, pos, plan=plan)
         torch.cuda.synchronize()
         raw.bsms_debug_set_timing(None)
-        t = buf.cpu().numpy().reshape(ntile, 16)[:, :7].astype(np.float64)
-        t = t[(t > 0).all(axis=1)]
+        full = buf.cpu().numpy().reshape(ntile, 16).astype(np.float64)
+        full = full[(full[:, :7] > 0).all(axis=1)]
+        t = full[:, :7]
+        if full[:, 11].max() > 0: print(f"  cycles of the stamped wave at the 12 chunk barriers: median {np.median(full[:, 11]):.0f}  p10 {np.percentile(full[:, 11], 10):.0f}  p90 {np.percentile(full[:, 11], 90):.0f}")
+        if (full[:, 15] > 0).all():
+            print(f"  shader clock over a tile (s_memtime / s_memrealtime): {np.median((t[:, 6] - t[:, 0]) / (full[:, 15] - full[:, 14])) * 100:.0f} MHz")
         d = np.diff(t, axis=1)
         names = ["issue gathers", "input stage (wait + fiber + relu)", "stage 0", "stage 1", "stage 2", "LayerNorm + y store"]
         span = t[:, 6].max() - t[:, 0].min()

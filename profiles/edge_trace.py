@@ -11,7 +11,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 fam = defaultdict(list)
 for r in trace:
     n = r["Kernel_Name"]
-    for key, tag in (("k_edge_fwd", "fwd"), ("k_edge_bwd", "bwd"), ("k_chain_fwd<8, 3, 0", "fwd"), ("k_chain_bwd<8, 1, 0", "bwd")):
+    for key, tag in (("k_edge_fwd", "fwd"), ("k_edge_bwd", "bwd"), ("k_edge32_fwd", "fwd"), ("k_edge32_bwd", "bwd"),
+                     ("k_chain_fwd<8, 3, 0", "fwd"), ("k_chain_bwd<8, 1, 0", "bwd")):
         if key in n:
             fam[tag].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), n.split("k_")[1][:22]))
 unet = [0, 1, 2, 3, 4, 5, 4, 3, 2, 1, 0]
