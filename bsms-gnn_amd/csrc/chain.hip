@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_prepack(PackTable tab) {
     }
     return;
   }
-  const int nb = d.N >> 4, chf = kChunkHdrFloats + nb * 768;
+  const int nb = d.N >> 4, planes = d.bf16 ? 1 : 3, chf = kChunkHdrFloats + nb * 256 * planes;   // bf16 precision: one plane
   const int total = (d.K >> 5) * chf;
   unsigned* dst = reinterpret_cast<unsigned*>(d.dst);
   for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_prepack(PackTable tab) {
       continue;
     }
     const int q = w - kChunkHdrFloats;
-    const int v = q & 3, lane = (q >> 2) & 63, tp = q >> 8, plane = tp % 3, t = tp / 3;
+    const int v = q & 3, lane = (q >> 2) & 63, tp = q >> 8, plane = tp % planes, t = tp / planes;
     unsigned piece[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -233,11 +233,12 @@ __device__ __forceinline__ float row_sum(const f32x4 (&v)[NB]) {
 // until its activation stores had reached memory -- MFMA phases and HBM phases then add up instead of
 // overlapping (measured: kernel time = MFMA time + store time).  Compute waves execute NO vmcnt wait in the
 // steady state; their stores drain in the background.
-template <int NB>
+// PL: bf16 planes per weight (3 = the exact fp32 split; 1 = the bf16 precision, whose packs carry the rounded weight only)
+template <int NB, int PL = 3>
 struct Ring {
   static constexpr int D = NB * 16;
   static constexpr int NCH = NB / 2;                          // chunks per stage (one per 32-feature K block)
-  static constexpr int CHF = kChunkHdrFloats + NB * 768;      // floats per chunk
+  static constexpr int CHF = kChunkHdrFloats + NB * 256 * PL; // floats per chunk
   static constexpr int CH4 = CHF / 4;                         // float4 per chunk
   static constexpr int PER = CHF / 256;                       // LDS-DMA instructions (1 KB each) per chunk
   static constexpr int NR = 3;                                // ring depth
@@ -259,15 +260,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 }
 
 // the loader wave's whole life
-template <int NB>
-__device__ __forceinline__ float* ring_side(float4* lds) { return reinterpret_cast<float*>(lds + Ring<NB>::NR * Ring<NB>::CH4); }
+template <int NB, int PL = 3>
+__device__ __forceinline__ float* ring_side(float4* lds) { return reinterpret_cast<float*>(lds + Ring<NB, PL>::NR * Ring<NB, PL>::CH4); }
 
 // `side` (nullable, 8*D floats in HBM): copied once into the side table; the compute waves wait for it at one extra
 // barrier before their first tile.
-template <int NB>
+template <int NB, int PL = 3>
 __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles,
                                            const float* side = nullptr) {
-  using R = Ring<NB>;
+  using R = Ring<NB, PL>;
   __builtin_amdgcn_s_setprio(3);                   // the loader must never be the wave the others wait for
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
   if (side) {
@@ -345,8 +346,8 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
                                            bool from_header, float* store_base = nullptr, int64_t store_off = -1,
                                            int store_mode = 0, int64_t mask_rows = 0,
                                            unsigned long long* waited = nullptr, int64_t row = 0, int64_t nrows = 0) {
-  using R = Ring<NB>;
   if constexpr (BF) {
+    using R = Ring<NB, 1>;
     u32x4 bb[NB / 2];
     round_block<NB>(act, 0, bb[0]);
     const bool st = store_base != nullptr && store_off >= 0;
@@ -370,7 +371,7 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
       const float4* body = cur + kChunkHdrFloats / 4 + lane;
 #pragma unroll
       for (int t = 0; t < NB; t += 2) {
-        const float4 h0 = body[(t * 3 + 0) * 64], h1 = body[(t * 3 + 3) * 64];
+        const float4 h0 = body[t * 64], h1 = body[(t + 1) * 64];   // one plane per pack
         acc[t] = mma(h0, bb[c], acc[t]);
         acc[t + 1] = mma(h1, bb[c], acc[t + 1]);
         if (t == 0) {
@@ -381,6 +382,7 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
     }
     return;
   }
+  using R = Ring<NB>;
   // The per-element VALU work of a stage (three-way split, sign bits) is spread over the chunks instead of sitting
   // in front of the first MFMA: only K block 0 is split up front, block c + 1 is split in the shadow of chunk c's
   // MFMAs (an MFMA occupies the issue port for 4 of its 16 cycles).
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   if (wave == kComputeWaves) {  // loader wave (uniform branch)
-    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
+    loader_run<NB, BF ? 1 : 3>(a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
     return;
   }
   // IN_EDGE: the fiber weights are read from the LDS side table (read from HBM/L2 they cost one dependent round
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   const float* w0t = a.w0t;
   if (IN == IN_EDGE) {
     lds_barrier();
-    w0t = ring_side<NB>(lds);
+    w0t = ring_side<NB, BF ? 1 : 3>(lds);
   }
   int slot = 0;  // ring slot of the next chunk; runs on across this workgroup's tiles exactly like the loader's
   // Persistent workgroups: the grid is sized to what the chip holds at once and strides over the tiles, so a CU
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   if (wave == kComputeWaves) {  // loader wave (uniform branch)
-    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles);
+    loader_run<NB, BF ? 1 : 3>(a.wseq, a.nseq, lds, lane, a.ntiles);
     return;
   }
   int slot = 0;  // ring slot of the next chunk, across this workgroup's tiles
