@@ -230,7 +230,7 @@ extern "C" int bsms_side_lanes_join(bsms_stream_t stream) {
   if ((rc = side_lane(&lane0, 0)) || (rc = side_lane(&lane1, 1))) return rc;
   hipStream_t st = as_stream(stream);
   for (int slot = 0; slot < 2; ++slot)   // a slot nobody marked is an event that was never recorded: the wait is a no-op
-    if ((rc = side_wait_mark(lane0, slot, st)) || (rc = side_wait_mark(lane1, slot, st))) return rc;
+    if ((!gmp_marks_chained() && (rc = side_wait_mark(lane0, slot, st))) || (rc = side_wait_mark(lane1, slot, st))) return rc;
   return BSMS_OK;
 }
 
@@ -268,7 +268,7 @@ extern "C" int bsms_bsgmp_bwd_ex(const bsms_plan_t* const* plans, const float* c
   auto run_block = [&](int level, const float* x, const float* g_in, int k, float* gx) -> int {
     const int slot = nblk & 1;
     int r;
-    if (marked[slot] && ((r = side_wait_mark(lane0, slot, st)) || (r = side_wait_mark(lane1, slot, st)))) return r;
+    if (marked[slot] && ((!gmp_marks_chained() && (r = side_wait_mark(lane0, slot, st))) || (r = side_wait_mark(lane1, slot, st)))) return r;
     ++nblk;
     marked[slot] = true;
     return gmp_bwd_core(plans[level], x, pos_l[level], g_in, B, D, p, pstride_l[level], hidden, block(params, k, hidden), v.gmp[k],
@@ -304,6 +304,6 @@ extern "C" int bsms_bsgmp_bwd_ex(const bsms_plan_t* const* plans, const float* c
   // that touches neither `work` nor `grads` and joins the lanes itself afterwards (BSMS_BWD_DEFER_JOIN)
   if (flags & BSMS_BWD_DEFER_JOIN) return BSMS_OK;
   for (int slot = 0; slot < 2; ++slot)
-    if (marked[slot] && ((rc = side_wait_mark(lane0, slot, st)) || (rc = side_wait_mark(lane1, slot, st)))) return rc;
+    if (marked[slot] && ((!gmp_marks_chained() && (rc = side_wait_mark(lane0, slot, st))) || (rc = side_wait_mark(lane1, slot, st)))) return rc;
   return BSMS_OK;
 }

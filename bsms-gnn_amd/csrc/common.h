@@ -56,6 +56,7 @@ int side_join(SideLane* lane, hipStream_t main);     // main waits for side
 // under the gradient chain of block k+1 and only waits for them before block k+2 reuses their scratch (bsgmp.hip).
 int side_mark(SideLane* lane, int slot);
 int side_wait_mark(SideLane* lane, int slot, hipStream_t main);
+int side_mark_chain(SideLane* a, SideLane* b, int slot);   // b's mark covers a's: wait for b only
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- internal entry points shared between translation units (not part of the C ABI)
@@ -74,6 +75,7 @@ int gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, int64_
                  void* packs_base, bool do_prepack, const float* resid2, hipStream_t stream, int precision = BSMS_F32);
 // `defer_slot` < 0: the side lanes are joined before returning (ABI semantics).  0/1: they are only MARKED in that slot;
 // the caller joins later with side_wait_mark on both lanes and must not touch `work` or read `grads` before that.
+bool gmp_marks_chained();   // gmp.hip: waiting for lane 1's mark of a slot is enough
 int gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, const float* grad_out, int64_t B, int64_t D,
                  int64_t p, int64_t pos_bstride, int hidden, const float* const* params, const void* saved, void* work,
                  float* grad_x, float* const* grads, int defer_slot, hipStream_t stream, int precision = BSMS_F32);

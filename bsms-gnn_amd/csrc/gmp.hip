@@ -304,6 +304,9 @@ struct LaneScope {
 };
 }  // namespace
 
+// deferred-join mode: does lane 1's mark cover lane 0's (side_mark_chain)?  True unless an experiment switch disables a lane.
+bool bsms::gmp_marks_chained() { return !(g_debug_flags & 8) && !(g_debug_flags & 32); }
+
 int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, const float* grad_out, int64_t B, int64_t D,
                        int64_t p, int64_t pos_bstride, int H, const float* const* params, const void* saved, void* work,
                        float* grad_x, float* const* grads, int defer_slot, hipStream_t s, int precision) {
@@ -390,10 +393,10 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   SideLane* lane2 = nullptr;
   hipStream_t s2 = s;
   const bool overlap2 = overlap && !(g_debug_flags & 32);
+  bool lane2_forked = false;   // its first fork is only needed by the unfused small-wgrad path; the fused path forks once, below
   if (overlap2) {
-    if ((rc = side_lane(&lane2, 1)) || (rc = side_fork(lane2, s))) return rc;
+    if ((rc = side_lane(&lane2, 1))) return rc;
     s2 = lane2->stream;
-    scope2.lane = lane2;
   }
   // gradient of the first edge Linear w.r.t. the two per-node projections -- and, in the same pass over gE[0], the
   // partial sums of its fiber columns and bias (rowsum.hip: k_rowsum_pair_fiber); only their small reduction is left
@@ -407,11 +410,20 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
                                        reinterpret_cast<float*>(wk.sw), small_wgrad_part_blocks(wk.sw_bytes, (int)D), &nwg, s, bf))) return rc;
   BSMS_REQUIRE(nwg > 0 || !bf, BSMS_E_UNSUPPORTED, "gmp_bwd: bf16 precision needs the fused scatter kernel (D = 128 / 256, pos_dim <= 3)");
   if (nwg == 0) {   // shape not built into the fused kernel (D < 128, pos_dim > 3): separate passes
+    if (overlap2) {
+      if ((rc = side_fork(lane2, s))) return rc;
+      scope2.lane = lane2;
+      lane2_forked = true;
+    }
     if ((rc = rowsum_source_and_target(plan, wk.gE[0], B, D, wk.dPs, wk.dPd, s))) return rc;
     if ((rc = launch_small_wgrad(sw, wk.sw, s2))) return rc;
   }
+  (void)lane2_forked;
   // x-columns of W0_edge (the two projections)
-  if (overlap2 && (rc = side_fork(lane2, s))) return rc;   // lane 2 additionally waits for dPs / dPd (and the partials)
+  if (overlap2) {   // lane 2 waits for dPs / dPd (and the partials)
+    if ((rc = side_fork(lane2, s))) return rc;
+    scope2.lane = lane2;
+  }
   if (nwg > 0 && (rc = launch_small_reduce(sw, wk.sw, nwg, s2))) return rc;
   {
     WgradJob jobs[2] = {};
@@ -430,6 +442,11 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.wp0b = reinterpret_cast<const float4*>(sv.e_wjt);
     a.y = grad_x; a.accumulate = 1;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_PLAIN, a, s))) return rc;
+  }
+  if (defer_slot >= 0 && scope1.lane && scope2.lane) {   // deferred join: one event covers both lanes (lane 2's mark waits for lane 1's)
+    SideLane *a = scope1.lane, *b = scope2.lane;
+    scope1.lane = scope2.lane = nullptr;
+    return side_mark_chain(a, b, defer_slot);
   }
   if ((rc = scope1.finish()) || (rc = scope2.finish())) return rc;
   return BSMS_OK;

@@ -57,6 +57,15 @@ int side_mark(SideLane* lane, int slot) {
   BSMS_HIP_CHECK(hipEventRecord(lane->done_ev[slot & 1], lane->stream));
   return BSMS_OK;
 }
+// both lanes' work so far as ONE event: lane `b` waits for lane `a`'s mark and records its own; a later
+// side_wait_mark(b, slot, main) then covers both (one barrier packet on the caller's stream instead of two)
+int side_mark_chain(SideLane* a, SideLane* b, int slot) {
+  std::lock_guard<std::mutex> lock(g_lane_mu);
+  BSMS_HIP_CHECK(hipEventRecord(a->done_ev[slot & 1], a->stream));
+  BSMS_HIP_CHECK(hipStreamWaitEvent(b->stream, a->done_ev[slot & 1], 0));
+  BSMS_HIP_CHECK(hipEventRecord(b->done_ev[slot & 1], b->stream));
+  return BSMS_OK;
+}
 int side_wait_mark(SideLane* lane, int slot, hipStream_t main) {
   std::lock_guard<std::mutex> lock(g_lane_mu);
   BSMS_HIP_CHECK(hipStreamWaitEvent(main, lane->done_ev[slot & 1], 0));
