@@ -35,6 +35,7 @@ constexpr int kMaxStages = 8;   // max Linear layers per MLP handled by one chai
 constexpr int kComputeWaves = 4;                       // compute waves per workgroup (each owns 16 rows)
 constexpr int kTileRows = kComputeWaves * 16;          // rows of x per workgroup
 constexpr int kChainThreads = (kComputeWaves + 1) * 64;  // + 1 loader wave
+constexpr int kChainMaxThreads = 8 * 64;               // generic chain kernels: up to 7 compute waves (launcher's choice)
 constexpr int kChunkHdrFloats = 256;                     // 1 KB chunk header (bias)
 // Precision of the EDGE-level tensors of a GMP block (include/bsms_hip.h: bsms_precision).  BF16: the saved edge
 // activations, the messages y and the edge layer gradients are stored as bf16 and the edge MLP's products take bf16
@@ -46,7 +47,7 @@ constexpr size_t mask_words_per_row(int64_t D) { return size_t(4) * (D <= 128 ? 
 // kPadRows rows, the edge kernels with two row blocks per wave): the stores then need no per-lane bounds test (rows
 // past R hold garbage nobody reads; the sign bits start after the padding and are padded the same way).
 constexpr int kPadRows = 2 * kTileRows;
-constexpr size_t pad_rows(size_t rows) { return (rows + kPadRows - 1) / kPadRows * kPadRows; }
+constexpr size_t pad_rows(size_t rows) { return (rows + kPadRows - 1) / kPadRows * kPadRows + kPadRows; }   // + one tile: tiles of 80..112 rows do not divide it
 constexpr size_t act_floats(size_t rows, int64_t D) { return pad_rows(rows) * (size_t(D) + mask_words_per_row(D)); }
 // row pitch (floats) of the saved fiber tensor: p + 1 values padded to one or two 16-byte pieces
 constexpr int fiber_ld(int64_t p) { return p + 1 <= 4 ? 4 : 8; }

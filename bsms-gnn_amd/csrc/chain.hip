@@ -493,11 +493,12 @@ __device__ __forceinline__ float dot_features(const f32x4 (&v)[NB], const float*
 // TIMING (experiments, profiles/tile_timeline.py): phase stamps of wave 0; a separate instantiation so that the
 // production kernel carries none of it.
 template <int NB, int IN, int OUT, bool TIMING = false, bool BF = false>
-__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_fwd(ChainFwdArgs a) {
+__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  if (wave == kComputeWaves) {  // loader wave (uniform branch)
+  const int cw = int(blockDim.x >> 6) - 1;   // compute waves of this launch (4..7, chosen by the launcher); the last wave loads
+  if (wave == cw) {  // loader wave (uniform branch)
     loader_run<NB, BF ? 1 : 3>(a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
     return;
   }
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(N
   // never waits for the dispatcher to refill a slot (measured: 20-35 % of slot time was empty with one
   // workgroup per tile) and the loader is already fetching the next tile's first chunk during this epilogue.
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-  const int64_t row = int64_t(tile) * kTileRows + wave * 16 + (lane & 15);
+  const int64_t row = int64_t(tile) * (16 * cw) + wave * 16 + (lane & 15);
   const bool live = row < a.R;
   const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
   const int64_t roff = live ? row * D : -1;  // row offset for stores; negative = no store
@@ -683,17 +684,18 @@ __device__ __forceinline__ void mask_by(f32x4 (&gr)[NB], const float* act_row, i
 }
 
 template <int NB, int GIN, int FIRST, bool BF = false>
-__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_bwd(ChainBwdArgs a) {
+__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  if (wave == kComputeWaves) {  // loader wave (uniform branch)
+  const int cw = int(blockDim.x >> 6) - 1;   // compute waves of this launch (4..7, chosen by the launcher); the last wave loads
+  if (wave == cw) {  // loader wave (uniform branch)
     loader_run<NB, BF ? 1 : 3>(a.wseq, a.nseq, lds, lane, a.ntiles);
     return;
   }
   int slot = 0;  // ring slot of the next chunk, across this workgroup's tiles
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {  // persistent workgroups (see k_chain_fwd)
-  const int64_t row = int64_t(tile) * kTileRows + wave * 16 + (lane & 15);
+  const int64_t row = int64_t(tile) * (16 * cw) + wave * 16 + (lane & 15);
   const bool live = row < a.R;
   const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
   const int64_t roff = live ? row * D : -1;  // row offset for stores; negative = no store
@@ -1228,6 +1230,26 @@ void k_edge_bwd(ChainBwdArgs a) {
 template <int NB>
 constexpr int resident_per_cu() { return NB <= 4 ? 4 : NB == 8 ? 2 : 1; }
 
+// Compute waves per workgroup of a generic chain launch: 4 (64-row tiles), or up to 7 when that makes the launch fit ONE
+// round of resident workgroups.  A workgroup streams the whole weight set once per tile (~23 us for the node MLP: the
+// LDS-DMA rate of a CU), so a second, nearly empty round costs as much as the first: the level-0 node launches of the
+// airfoil step (41 864 rows = 655 tiles of 64 on 512 slots) run as 437 tiles of 96 rows instead.  The SPI accounts a
+// 5-wave workgroup like an 8-wave one anyway (resident_per_cu), so the extra waves use slots that were empty.
+template <int NB>
+int chain_compute_waves(int64_t R) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int64_t slots = int64_t(cus) * resident_per_cu<NB>();
+  if (NB < 8 || ceil_div(R, kTileRows) <= slots) return kComputeWaves;
+  const int64_t need = ceil_div(R, slots * 16);   // waves per workgroup for one round
+  return need <= 7 ? (int)need : kComputeWaves;
+}
+
 template <int NB>
 unsigned persistent_grid(int64_t ntiles) {
   static int cus = 0;
@@ -1335,14 +1357,16 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
     int rc = BSMS_OK;
     if (launch_edge_fwd<NB>(a, s, rc)) return rc;
   }
-  a.ntiles = (int)ceil_div(a.R, kTileRows);
+  const int cw = (IN == IN_EDGE) ? kComputeWaves : chain_compute_waves<NB>(a.R);
+  const dim3 threads((cw + 1) * 64);
+  a.ntiles = (int)ceil_div(a.R, 16 * cw);
   bool launched = false;
   if constexpr (NB == 8 && IN == IN_EDGE) {   // the only instantiation with stamps
     if (a.timing) {
       static const hipError_t tattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, true>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
       BSMS_REQUIRE(tattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (timing build)");
-      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, true>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       launched = true;
     }
   }
@@ -1351,13 +1375,13 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
       static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, true>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
       BSMS_REQUIRE(battr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (bf16 build)");
-      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, true>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       launched = true;
     }
   }
   BSMS_REQUIRE(launched || !a.bf16, BSMS_E_UNSUPPORTED, "chain_fwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
   if (!launched)
-    hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+    hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -1389,22 +1413,24 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", lds);
-  a.ntiles = (int)ceil_div(a.R, kTileRows);
+  const int cw = (GIN == G_EDGE_LN) ? kComputeWaves : chain_compute_waves<NB>(a.R);
+  const dim3 threads((cw + 1) * 64);
+  a.ntiles = (int)ceil_div(a.R, 16 * cw);
   if constexpr ((NB == 8 || NB == 16) && GIN == G_EDGE_LN && FIRST == F_NONE) {
     int rc = BSMS_OK;
     if (launch_edge_bwd<NB>(a, s, rc)) return rc;
-    a.ntiles = (int)ceil_div(a.R, kTileRows);
+    a.ntiles = (int)ceil_div(a.R, 16 * cw);
     if (a.bf16) {
       static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
       BSMS_REQUIRE(battr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve LDS (bf16 build)");
-      hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, true>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+      hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       BSMS_LAUNCH_CHECK();
       return BSMS_OK;
     }
   }
   BSMS_REQUIRE(!a.bf16, BSMS_E_UNSUPPORTED, "chain_bwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
-  hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3(persistent_grid<NB>(a.ntiles)), dim3(kChainThreads), lds, s, a);
+  hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
