@@ -563,6 +563,12 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
 extern "C" int bsms_mlp_bwd(const float* x, const float* grad_y, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim,
                             int H, int layer_norm, const float* const* params, const void* saved, void* work,
                             float* grad_x, float* const* grads, bsms_stream_t stream) {
+  return bsms_mlp_bwd_ex(x, grad_y, R, in_dim, D, out_dim, H, layer_norm, params, saved, work, grad_x, grads, 0, stream);
+}
+
+extern "C" int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim,
+                               int H, int layer_norm, const float* const* params, const void* saved, void* work,
+                               float* grad_x, float* const* grads, int flags, bsms_stream_t stream) {
   int rc = check_mlp(R, in_dim, D, out_dim, H, layer_norm, "mlp_bwd");
   if (rc) return rc;
   BSMS_REQUIRE(params && grads && saved && work, BSMS_E_INVALID_ARG, "mlp_bwd: null argument");
@@ -604,6 +610,13 @@ extern "C" int bsms_mlp_bwd(const float* x, const float* grad_y, int64_t R, int6
   }
   if (rc) return rc;
 
+  // BSMS_BWD_DEFER_JOIN: grad_x is complete in stream order here; the weight gradients go to side lane 0 and the caller
+  // joins later (bsms_side_lanes_join) -- the fused step runs the decoder's weight gradients under the U-Net's first block
+  if (flags & BSMS_BWD_DEFER_JOIN) {
+    SideLane* lane = nullptr;
+    if ((rc = side_lane(&lane, 0)) || (rc = side_fork(lane, s))) return rc;
+    s = lane->stream;
+  }
   WgradJob jobs[kMaxWgradJobs] = {};
   int nj = 0;
   for (int l = (kind == MLP_SMALL_LN ? 1 : 0); l <= top; ++l) {
@@ -619,12 +632,16 @@ extern "C" int bsms_mlp_bwd(const float* x, const float* grad_y, int64_t R, int6
   if (kind == MLP_SMALL_LN) {          // dW0[f][k] = sum_r g0[r][f] x[r][k] ; db0 = colsum g0
     sa.G = wk.g[0]; sa.S = x; sa.S_cols = (int)in_dim;
     sa.out = grads[0]; sa.os = 1; sa.of = in_dim; sa.colsum = grads[1];
-    return launch_small_wgrad(sa, wk.sw, s);
-  }
-  if (kind == MLP_ROWS_SMALL) {        // dW_H[c][f] = sum_r dy[r][c] a_{H-1}[r][f] ; db_H = colsum dy
+    rc = launch_small_wgrad(sa, wk.sw, s);
+  } else if (kind == MLP_ROWS_SMALL) {        // dW_H[c][f] = sum_r dy[r][c] a_{H-1}[r][f] ; db_H = colsum dy
     sa.G = sv.act[H - 1]; sa.S = grad_y; sa.S_cols = (int)out_dim;
     sa.out = grads[2 * H]; sa.os = D; sa.of = 1; sa.colsum_S = grads[2 * H + 1];
-    return launch_small_wgrad(sa, wk.sw, s);
+    rc = launch_small_wgrad(sa, wk.sw, s);
+  }
+  if (rc) return rc;
+  if (flags & BSMS_BWD_DEFER_JOIN) {   // visible to bsms_side_lanes_join even if nothing else uses the lane afterwards
+    SideLane* lane = nullptr;
+    if ((rc = side_lane(&lane, 0)) || (rc = side_mark(lane, 0))) return rc;
   }
   return BSMS_OK;
 }

@@ -89,6 +89,7 @@ class FusedStep:
                  work=u8(max(L.bsms_mlp_work_bytes(R, C + 1, D, D, H), L.bsms_mlp_work_bytes(R, D, D, C, H),
                              L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, H), L.bsms_sim_work_bytes(R))),
                  work_enc=u8(L.bsms_mlp_work_bytes(R, C + 1, D, D, H)),   # the encoder's backward overlaps the U-Net's last weight gradients
+                 work_dec=u8(L.bsms_mlp_work_bytes(R, D, D, C, H)),       # the decoder's weight gradients run under the U-Net's first block
                  in_static=None)
         self._shape_key, self._buf, self._graphs = key, b, None
         return b
@@ -124,8 +125,8 @@ class FusedStep:
         ck(L.bsms_sim_loss_bwd(b["pred"].data_ptr(), tar.data_ptr(), mask.data_ptr(), R, C, no._E_data.data_ptr(),
                                no._E_data_squared.data_ptr(), no.std_eps.data_ptr(), b["sums"].data_ptr(), b["loss"].data_ptr(),
                                b["g_np"].data_ptr(), s), "bsms_sim_loss_bwd")
-        ck(L.bsms_mlp_bwd(b["h1"].data_ptr(), b["g_np"].data_ptr(), R, D, D, C, H, 0, t["dec"][0][0], b["s_dec"].data_ptr(),
-                          work.data_ptr(), b["gh1"].data_ptr(), t["dec"][1][0], s), "bsms_mlp_bwd(decode)")
+        ck(L.bsms_mlp_bwd_ex(b["h1"].data_ptr(), b["g_np"].data_ptr(), R, D, D, C, H, 0, t["dec"][0][0], b["s_dec"].data_ptr(),
+                             b["work_dec"].data_ptr(), b["gh1"].data_ptr(), t["dec"][1][0], 1, s), "bsms_mlp_bwd(decode)")   # 1 = BSMS_BWD_DEFER_JOIN
         ewp, keep = _abi.ptr_array([e.data_ptr() for e in ews])
         # BSMS_BWD_DEFER_JOIN: the weight gradients of the last (level-0) block are still running on the engine's side
         # streams (~0.2 ms on half the chip) while the encoder's backward -- own scratch, own gradient slots -- runs here

@@ -201,6 +201,11 @@ int bsms_bsgmp_bwd_ex(const bsms_plan_t* const* plans, const float* const* ew, i
                       const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
                       int precision, int flags, bsms_stream_t stream);
 int bsms_side_lanes_join(bsms_stream_t stream);
+/* bsms_mlp_bwd with `flags`.  BSMS_BWD_DEFER_JOIN: `grad_x` is complete in stream order when the call returns, the weight
+ * gradients run on an internal side stream; same contract as above (`work`, `grads`, bsms_side_lanes_join). */
+int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int H,
+                    int layer_norm, const float* const* params, const void* saved, void* work, float* grad_x,
+                    float* const* grads, int flags, bsms_stream_t stream);
 
 
 /* ---------------------------------------------------------------- A10-A12: model glue + loss -
