@@ -20,10 +20,12 @@ for lvl in (0, 3):
         x = torch.randn(8, n0, 128, device="cuda", requires_grad=grad)
         ntile = (8 * e0 + 63) // 64
         buf = torch.zeros(ntile * 16, dtype=torch.int64, device="cuda")
-        for _ in range(3):
+        ctx = torch.enable_grad() if grad else torch.no_grad()   # inference = the no-save kernel (stores only the messages)
+        with ctx:
+            for _ in range(3):
+                gmp(x, g0, pos, plan=plan)
+            raw.bsms_debug_set_timing(buf.data_ptr())
             gmp(x, g0, pos, plan=plan)
-        raw.bsms_debug_set_timing(buf.data_ptr())
-        gmp(x, g0, pos, plan=plan)
         torch.cuda.synchronize()
         raw.bsms_debug_set_timing(None)
         full = buf.cpu().numpy().reshape(ntile, 16).astype(np.float64)
