@@ -1009,12 +1009,13 @@ struct EdgeTile {
 };
 
 template <int NB, int RB, bool SAVE>
-__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(EdgeTile<NB, RB>::waves_per_eu)))
+__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(EdgeTile<NB, RB>::waves_per_eu)))
 void k_edge_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  if (wave == kComputeWaves) {  // loader wave (uniform branch)
+  const int cw = int(blockDim.x >> 6) - 1, tile_rows = 16 * RB * cw;   // compute waves of this launch (launcher's choice); the last wave loads
+  if (wave == cw) {  // loader wave (uniform branch)
     loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles, a.w0t);
     return;
   }
@@ -1024,7 +1025,7 @@ void k_edge_fwd(ChainFwdArgs a) {
   auto fetch_endpoints = [&](int tile, int (&i)[RB], int (&j)[RB], int (&b)[RB]) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const int64_t r = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
+      const int64_t r = int64_t(tile) * tile_rows + wave * (16 * RB) + rb * 16 + (lane & 15);
       const EdgeRef e = edge_ref(unsigned(r < a.R ? r : 0), unsigned(a.E), rcpE);   // a lane past the end reads row 0
       i[rb] = a.src[e.q];
       j[rb] = a.dst[e.q];
@@ -1052,7 +1053,7 @@ void k_edge_fwd(ChainFwdArgs a) {
     // ---- input stage: relu(Ps[src] + Pd[dst] + Wf . [pos_i - pos_j, |pos_i - pos_j|])   (ops/basic.py:70-92)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      row[rb] = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
+      row[rb] = int64_t(tile) * tile_rows + wave * (16 * RB) + rb * 16 + (lane & 15);
       off[rb] = pair_offsets<NB>(wave * (16 * RB) + rb * 16 + (lane & 15), lane);                         // within the tile
       moff[rb] = unsigned(((wave * (16 * RB) + rb * 16 + (lane & 15)) * (4 * mask_words<NB>()) + lg * mask_words<NB>()) * 4);
       const int i = ni[rb], j = nj[rb], b = nbat[rb];
@@ -1106,8 +1107,8 @@ void k_edge_fwd(ChainFwdArgs a) {
     float* pending = a.store_in;   // uniform; non-null when SAVE (launcher)
     stamp();
     for (int l = 0; l < a.nstage; ++l) {
-      float* st_tile = SAVE ? pending + int64_t(tile) * (EdgeTile<NB, RB>::rows * D) : nullptr;   // uniform
-      unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (EdgeTile<NB, RB>::rows * 4 * mask_words<NB>()) : nullptr;
+      float* st_tile = SAVE ? pending + int64_t(tile) * (tile_rows * D) : nullptr;   // uniform
+      unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (tile_rows * 4 * mask_words<NB>()) : nullptr;
       stage_rb<NB, RB, SAVE, true, true>(acc, act, lds, slot, lane, st_tile, bits_tile, off, moff);   // acc = bias + W act
       stamp();
       if (l + 1 < a.nstage) {
@@ -1144,12 +1145,13 @@ void k_edge_fwd(ChainFwdArgs a) {
 }
 
 template <int NB, int RB>
-__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(EdgeTile<NB, RB>::waves_per_eu)))
+__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(EdgeTile<NB, RB>::waves_per_eu)))
 void k_edge_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16, W = mask_words<NB>();
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  if (wave == kComputeWaves) {  // loader wave (uniform branch)
+  const int cw = int(blockDim.x >> 6) - 1, tile_rows = 16 * RB * cw;   // compute waves of this launch (launcher's choice); the last wave loads
+  if (wave == cw) {  // loader wave (uniform branch)
     loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles);
     return;
   }
@@ -1157,7 +1159,7 @@ void k_edge_bwd(ChainBwdArgs a) {
   auto fetch_targets = [&](int tile, int64_t (&node)[RB]) {   // node row (b * N + dst) of this lane's rows, one tile ahead
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const int64_t r = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
+      const int64_t r = int64_t(tile) * tile_rows + wave * (16 * RB) + rb * 16 + (lane & 15);
       const EdgeRef e = edge_ref(unsigned(r < a.R ? r : 0), unsigned(a.E), rcpE);
       node[rb] = int64_t(e.b) * a.N + a.dst[e.q];
     }
@@ -1173,7 +1175,7 @@ void k_edge_bwd(ChainBwdArgs a) {
     float rs[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {   // autograd of scatter_sum: gather the node gradient by target; y, rstd of the row
-      row[rb] = int64_t(tile) * EdgeTile<NB, RB>::rows + wave * (16 * RB) + rb * 16 + (lane & 15);
+      row[rb] = int64_t(tile) * tile_rows + wave * (16 * RB) + rb * 16 + (lane & 15);
       rowc[rb] = row[rb] < a.R ? row[rb] : 0;
       off[rb] = pair_offsets<NB>(wave * (16 * RB) + rb * 16 + (lane & 15), lane);   // within the tile
       moff[rb] = 0;
@@ -1206,7 +1208,7 @@ void k_edge_bwd(ChainBwdArgs a) {
 #pragma unroll
         for (int w = 0; w < W; ++w)
           mbits[rb][w] = reinterpret_cast<const unsigned*>(a.mask[k] + pad_rows(a.R) * D)[rowc[rb] * (4 * W) + lg * W + w];
-      stage_rb<NB, RB, true, false, false>(acc, g, lds, slot, lane, pending + int64_t(tile) * (EdgeTile<NB, RB>::rows * D), nullptr, off, moff);
+      stage_rb<NB, RB, true, false, false>(acc, g, lds, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -1285,14 +1287,28 @@ inline int edge_rb_mode() {
 #endif
 }
 
+// Compute waves per workgroup of an edge launch.  At D = 256 a tile streams 1.2 MB of weight packs (8 chunks of 49 KB per
+// layer) and the LDS-DMA stream of a CU, not the matrix pipe, sets the pace: 7 compute waves (112-row tiles; one workgroup
+// per CU, 8 waves = two per SIMD at the 256-VGPR budget) spread that stream over 1.75x the rows.  At D = 128 stream
+// and compute are level and larger tiles measured +-0 (profiles/r02_edge_levels.md): 4.
+template <int NB>
+constexpr int edge_compute_waves() {
+#ifdef BSMS_EDGE16_CW
+  return NB >= 16 ? BSMS_EDGE16_CW : kComputeWaves;
+#else
+  return NB >= 16 ? 7 : kComputeWaves;
+#endif
+}
+
 template <int NB, int RB, bool SAVE>
 int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes);
-  a.ntiles = (int)ceil_div(a.R, EdgeTile<NB, RB>::rows);
+  constexpr int cw = edge_compute_waves<NB>();
+  a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
-  hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE>), dim3(grid), dim3(kChainThreads), Ring<NB>::lds_bytes, s, a);
+  hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE>), dim3(grid), dim3((cw + 1) * 64), Ring<NB>::lds_bytes, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -1322,9 +1338,10 @@ int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes);
-  a.ntiles = (int)ceil_div(a.R, EdgeTile<NB, RB>::rows);
+  constexpr int cw = edge_compute_waves<NB>();
+  a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
-  hipLaunchKernelGGL((k_edge_bwd<NB, RB>), dim3(grid), dim3(kChainThreads), Ring<NB>::lds_bytes, s, a);
+  hipLaunchKernelGGL((k_edge_bwd<NB, RB>), dim3(grid), dim3((cw + 1) * 64), Ring<NB>::lds_bytes, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
