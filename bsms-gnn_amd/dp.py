@@ -163,7 +163,10 @@ class DataParallel:
         self.grads.finish()
         return loss
 
-    def sync_normalizers(self):
-        for m in self.model.modules():
-            if hasattr(m, "synchronize") and hasattr(m, "_E_data"):
-                m.synchronize(self.group)
+    def normalizers(self):
+        return [m for m in self.model.modules() if hasattr(m, "synchronize") and hasattr(m, "_E_data")]
+
+    def sync_normalizers(self, base=None):
+        """`base`: {normaliser: snapshot} of statistics all ranks already share (Trainer.restore before more warm-up)."""
+        for m in self.normalizers():
+            m.synchronize(self.group, None if base is None else base.get(m))

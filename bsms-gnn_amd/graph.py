@@ -4,6 +4,8 @@ reference-style call `GMP()(x, g, pos)` with a raw edge tensor `g` builds its CS
 The reference re-derives all indexing from `g` on every call (ops/basic.py:66-72); here `g` [2,E] int64
 is converted once into a destination-sorted CSR + source-sorted transpose held in HBM."""
 import ctypes as C
+import hashlib
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -66,6 +68,13 @@ class LevelPlan:
                 pass
 
 
+def _cache_capacity():
+    """Entries of the plan cache and of the interned-index table.  One mesh of L levels takes L+1 plans and 2L+1 index
+    tensors, so the default serves ~70 distinct 7-level meshes before anything is rebuilt (a variable-mesh dataset with
+    more should raise BSMS_PLAN_CACHE; an airfoil-size mesh pins ~2 MB of HBM per entry)."""
+    return max(int(os.environ.get("BSMS_PLAN_CACHE", "1024")), 8)
+
+
 def _key(t):
     st = t.untyped_storage()
     return (st.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t._version, str(t.device))
@@ -75,8 +84,8 @@ class _PlanCache:
     """LRU keyed by the identity of the index tensors' storage (+ version counter).  Each entry keeps
     the storages alive, so a cached address can never be recycled for a different graph."""
 
-    def __init__(self, capacity=64):
-        self.capacity = capacity
+    def __init__(self, capacity=None):
+        self.capacity = _cache_capacity() if capacity is None else capacity
         self._d = OrderedDict()
 
     def get(self, g, num_nodes, ids=None):
@@ -115,13 +124,16 @@ def clear_plan_cache():
 # interned by CONTENT while they are still on the host: equal content -> the same device tensor object -> the identity
 # keyed plan cache hits, and the edge lists are not re-uploaded either.
 _INTERNED = OrderedDict()
-_INTERN_CAPACITY = 64
+try:                                   # optional accelerator; the stdlib digest below is the fallback
+    import xxhash as _xxhash
+except ImportError:
+    _xxhash = None
 
 
 def _content_key(t):
-    import xxhash
-    a = np.ascontiguousarray(t.numpy())
-    return (tuple(t.shape), str(t.dtype), xxhash.xxh64_intdigest(a.view(np.uint8).reshape(-1)))
+    a = np.ascontiguousarray(t.numpy()).view(np.uint8).reshape(-1)
+    digest = _xxhash.xxh3_128_intdigest(a) if _xxhash is not None else hashlib.blake2b(a, digest_size=16).digest()
+    return (tuple(t.shape), str(t.dtype), digest)
 
 
 def intern_index(t, device, shared_batch_axis=False):
@@ -135,16 +147,18 @@ def intern_index(t, device, shared_batch_axis=False):
     if shared_batch_axis and t.dim() >= 2 and t.shape[0] >= 1 and bool((t == t[:1]).all()):
         first = t[0]
     key = (_content_key(first if first is not None else t), t.shape[0] if first is not None else -1, str(device))
+    src = first if first is not None else t
     hit = _INTERNED.get(key)
-    if hit is not None:
+    if hit is not None and torch.equal(hit[1], src):       # a digest match is confirmed on the content (host memcmp)
         _INTERNED.move_to_end(key)
-        return hit
+        return hit[0]
+    host = src.contiguous().clone()
     if first is not None:
-        dev = first.contiguous().to(device).unsqueeze(0).expand(t.shape[0], *first.shape)
+        dev = host.to(device).unsqueeze(0).expand(t.shape[0], *first.shape)
     else:
-        dev = t.to(device)
-    _INTERNED[key] = dev
-    if len(_INTERNED) > _INTERN_CAPACITY:
+        dev = host.to(device)
+    _INTERNED[key] = (dev, host)
+    if len(_INTERNED) > _cache_capacity():
         _INTERNED.popitem(last=False)
     return dev
 

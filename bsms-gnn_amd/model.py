@@ -54,15 +54,28 @@ class Normalizer(nn.Module):
         std = torch.sqrt(self._E_data_squared - self.mean() ** 2)
         return torch.max(torch.nan_to_num(std), self.std_eps)
 
-    def synchronize(self, group=None):
-        """Merge accumulators across ranks (weights add; means are weight-averaged)."""
+    def snapshot(self):
+        """(weight, count, weighted first / second moments) of the statistics held now -- the `base` of a later
+        `synchronize` when these statistics are already global (restored from a checkpoint)."""
+        w = self._acc_weight.data.clone()
+        return w, self._num_accumulations.data.clone(), self._E_data.data * w, self._E_data_squared.data * w
+
+    def synchronize(self, group=None, base=None):
+        """Merge accumulators across ranks (weights add; means are weight-averaged).  `base` (a `snapshot()`) is a
+        part of the statistics every rank already shares -- a restored checkpoint followed by more warm-up -- and
+        is counted once instead of once per rank."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             self.synced = True
             return
         w = self._acc_weight.data.clone()
-        buf = torch.cat([w, self._num_accumulations.data, self._E_data.data * w, self._E_data_squared.data * w])
+        parts = [w, self._num_accumulations.data.clone(), self._E_data.data * w, self._E_data_squared.data * w]
+        if base is not None:
+            parts = [a - b for a, b in zip(parts, base)]
+        buf = torch.cat(parts)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        if base is not None:
+            buf = buf + torch.cat(list(base))
         wsum = buf[0:1]
         self._acc_weight.data = wsum.clone()
         self._num_accumulations.data = buf[1:2].clone()
@@ -164,9 +177,3 @@ def masked_rmse(pred, tar, mask):
     """trainer/trainer.py:96-97."""
     se = (pred - tar) ** 2
     return torch.sqrt((se * mask).sum() / mask.sum() / se.shape[-1])
-
-
-def masked_se_sums(pred, tar, mask):
-    """The two global sums of the loss, for the data-parallel exact-RMSE exchange."""
-    se = (pred - tar) ** 2
-    return (se * mask).sum(), mask.sum()

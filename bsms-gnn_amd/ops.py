@@ -502,21 +502,36 @@ class _BSGMPFunction(torch.autograd.Function):
         return (gh, None, None, None, None, None, *grads)
 
 
+_PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    """Called by everything that updates parameters through raw pointers at the C ABI (trainer.FusedAdamW.step): such
+    writes do not touch the tensors' autograd version counters, so cached weight packs are keyed on this epoch too."""
+    _PARAM_EPOCH[0] += 1
+
+
 class InferenceSession:
     """State an autoregressive caller keeps between forward-only BSGMP calls (bsms_bsgmp_fwd_ex `reuse`): a PRIVATE work
     buffer holding the weight packs and the coarse positions of the previous call.  Packs are reused while the
-    parameters are unchanged (data pointers + version counters); positions only if the caller declares them static
-    (rollout: mesh_pos never changes, utils/rollout_utils.py:46)."""
+    parameters are unchanged (data pointers + version counters + the engine's parameter epoch, which the fused
+    optimizer bumps); positions only if the caller declares them static (rollout: mesh_pos never changes,
+    utils/rollout_utils.py:46) and the call has the same plans, batch and model geometry (the offsets inside the work
+    buffer depend on D / hidden / pos_dim).  `invalidate()` forgets both -- for callers that change parameters or
+    positions behind the engine's back."""
 
     def __init__(self, static_pos=False):
         self.static_pos, self.work, self.pkey, self.gkey = static_pos, None, None, None
 
-    def flags(self, params, plans, B, nbytes, device):
+    def invalidate(self):
+        self.pkey = self.gkey = None
+
+    def flags(self, params, plans, B, nbytes, device, geom=()):
         if self.work is None or self.work.numel() < nbytes or self.work.device != device:
             self.work = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             self.pkey = self.gkey = None
-        pkey = tuple((q.data_ptr(), q._version) for q in params)
-        gkey = (tuple(id(q) for q in plans), B)
+        pkey = (_PARAM_EPOCH[0], tuple((q.data_ptr(), q._version) for q in params))
+        gkey = (tuple(id(q) for q in plans), B, tuple(geom))
         reuse = (1 if pkey == self.pkey and gkey == self.gkey else 0) | (2 if self.static_pos and gkey == self.gkey else 0)
         self.pkey, self.gkey = pkey, gkey
         return reuse
@@ -537,7 +552,7 @@ def _bsgmp_infer(h, pos, plans, ews, hidden, params, session=None, prec=0):
     nbytes = L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden)
     reuse = 0
     if session is not None:
-        reuse = session.flags(params, plans, B, nbytes, h.device)
+        reuse = session.flags(params, plans, B, nbytes, h.device, geom=(D, p, hidden, prec, pos_bstride))
         work = session.work
     else:
         work = _workspace(h.device, nbytes)

@@ -56,8 +56,32 @@ class FusedStep:
             node_in, tar, mask = data[0].x.unsqueeze(0), data[0].y.unsqueeze(0), data[0].mask.unsqueeze(0)
             m_gs = [d.edge_index for d in data]
             m_ids = [data[i].face for i in range(len(m_gs) - 1)]
+        self._validate(node_in, tar, mask, m_gs, m_ids)
         f = lambda t: t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
         return f(node_in), f(tar), f(mask), m_gs, m_ids
+
+    def _validate(self, node_in, tar, mask, m_gs, m_ids):
+        """The C entries take raw pointers with sizes from cfg: a mis-shaped batch must fail HERE, like the shape
+        error PyTorch would raise in the reference (models/model.py:127-164), not read device memory out of bounds."""
+        cfg = self.model.cfg
+        C, p, depth = cfg.out_dim, self.model.pos_dim, cfg.unet_depth
+        if node_in.dim() != 3 or node_in.shape[-1] != C + p + 1:
+            raise RuntimeError(f"node_in must be [B, N, out_dim + pos_dim + 1 = {C + p + 1}], got {tuple(node_in.shape)}")
+        B, N = node_in.shape[0], node_in.shape[1]
+        if tuple(tar.shape) != (B, N, C):
+            raise RuntimeError(f"target must be [B, N, out_dim] = {(B, N, C)}, got {tuple(tar.shape)}")
+        if mask.numel() != B * N or (mask.dim() == 3 and tuple(mask.shape) != (B, N, 1)) or mask.dim() not in (2, 3):
+            raise RuntimeError(f"mask must be [B, N, 1] = {(B, N, 1)}, got {tuple(mask.shape)}")
+        if len(m_gs) != depth + 1 or len(m_ids) != depth:
+            raise RuntimeError(f"unet_depth = {depth} needs {depth + 1} edge lists and {depth} kept-id lists, "
+                               f"got {len(m_gs)} and {len(m_ids)}")
+        dev = node_in.device
+        for name, t in (("target", tar), ("mask", mask), *((f"m_gs[{i}]", g) for i, g in enumerate(m_gs)),
+                        *((f"m_ids[{i}]", g) for i, g in enumerate(m_ids))):
+            if t.device != dev:
+                raise RuntimeError(f"{name} is on {t.device}, node_in on {dev}: all tensors of a step must share one device")
+        if next(self.model.parameters()).device != dev:
+            raise RuntimeError(f"the model is on {next(self.model.parameters()).device}, the batch on {dev}")
 
     def _pointer_tables(self):
         m = self.model
@@ -156,7 +180,7 @@ class FusedStep:
         self._backward(b, tar, mask, ews, B, N)
         if world > 1:
             dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
-        return b["loss"][0]
+        return b["loss"][0].clone()       # the static buffer is overwritten by the next step: hand out a copy (4 bytes)
 
     def prediction(self):
         """[B,N,C] prediction of the last step (a static buffer: clone it to keep it)."""
@@ -188,4 +212,4 @@ class FusedStep:
         gb.replay()
         if world > 1:
             dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
-        return b["loss"][0]
+        return b["loss"][0].clone()

@@ -10,6 +10,7 @@ import torch
 
 from . import _abi
 from .dp import DataParallel
+from .ops import bump_param_epoch
 
 
 class WarmupCosineDecay:
@@ -58,6 +59,7 @@ class FusedAdamW:
             self.flat_p.numel(), float(self.lr if lr is None else lr), b1, b2, self.eps, self.wd, self.step_count,
             float(self.max_norm), self.grad_norm.data_ptr(), self._work.data_ptr(), torch.cuda.current_stream().cuda_stream),
             "bsms_adamw_step")
+        bump_param_epoch()           # raw-pointer update: invalidates weight packs cached by ops.InferenceSession
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
@@ -82,6 +84,7 @@ class Trainer:
         self.lr_scheduler = WarmupCosineDecay(opt_cfg.peak_lr, opt_cfg.warmup_steps, opt_cfg.decay_steps)
         self.train_step = 0
         self._synced = False
+        self._norm_base = None     # statistics every rank already shares (restore followed by warm-up)
 
     def move_to_device(self, data):
         """trainer/trainer.py:143 semantics (nested lists -> device), except that INDEX tensors (edge lists, kept ids)
@@ -126,8 +129,8 @@ class Trainer:
             loss = None
         else:
             if not self._synced:                                  # merge normaliser statistics once (dp.py)
-                self.dp.sync_normalizers()
-                self._synced = True
+                self.dp.sync_normalizers(self._norm_base)
+                self._synced, self._norm_base = True, None
             loss = self.dp.step_loss_backward(data, self.model_cfg.consistent_mesh)
             self.optimizer.step(self.lr_scheduler.lr())
             self.lr_scheduler.step()
@@ -148,6 +151,12 @@ class Trainer:
             self.optimizer.load_state_dict(st["opt"])
             self.lr_scheduler.last_epoch = st["epoch"]
             self.train_step = st["train_step"]
-        # restored normaliser statistics are already the merged ones: never re-run the cross-rank merge on them
-        # (it would multiply _acc_weight / _num_accumulations by the world size)
-        self._synced = True
+        # Restored normaliser statistics are already the merged ones.  If no warm-up follows they must not be merged
+        # again (it would multiply _acc_weight / _num_accumulations by the world size).  If warm-up does follow
+        # (restore_opt_state=False, no optimizer-state file, or a checkpoint taken during warm-up) every rank goes on
+        # accumulating its own shard on top of them: the merge then runs once after warm-up, over the per-rank
+        # additions only, with the restored part counted once (Normalizer.synchronize(base=...)).
+        if self._warming_up():
+            self._synced, self._norm_base = False, {m: m.snapshot() for m in self.dp.normalizers()}
+        else:
+            self._synced, self._norm_base = True, None

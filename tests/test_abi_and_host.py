@@ -195,3 +195,30 @@ def test_float32_and_float64_positions_really_differ(eng):
         b = eng.BistrideMultiLayerGraph(fe, 3, pos.shape[0], pos.astype(np.float64)).m_ids
         differ += any(x.shape != y.shape or not np.array_equal(x, y) for x, y in zip(a, b))
     assert differ >= 1
+
+
+def test_intern_index_confirms_content_and_needs_no_xxhash(eng, monkeypatch):
+    """graph.intern_index: equal content -> the same tensor object; a digest collision must not alias two meshes (the
+    hit is confirmed against a host copy); works without the optional xxhash package (stdlib blake2b)."""
+    from bsms_gnn_amd import graph
+    graph._INTERNED.clear()
+    a = torch.arange(40, dtype=torch.int64).reshape(2, 20)
+    t1 = graph.intern_index(a.clone(), "cpu")
+    assert graph.intern_index(a.clone(), "cpu") is t1
+    monkeypatch.setattr(graph, "_xxhash", None)
+    t2 = graph.intern_index(a.clone(), "cpu")            # other digest -> new entry, then stable
+    assert graph.intern_index(a.clone(), "cpu") is t2 and torch.equal(t2, a)
+    monkeypatch.setattr(graph, "_content_key", lambda t: ("collide",))
+    graph._INTERNED.clear()
+    x = graph.intern_index(a.clone(), "cpu")
+    y = graph.intern_index((a + 1).clone(), "cpu")       # same key, different content
+    assert torch.equal(x, a) and torch.equal(y, a + 1)
+    # shared batch axis: one slice kept, stride-0 view handed out
+    b = a.unsqueeze(0).repeat(4, 1, 1)
+    v = graph.intern_index(b, "cpu", shared_batch_axis=True)
+    assert v.shape == b.shape and v.stride(0) == 0 and torch.equal(v, b)
+    monkeypatch.setenv("BSMS_PLAN_CACHE", "8")
+    for k in range(20):
+        graph.intern_index(a + 100 + k, "cpu")
+    assert len(graph._INTERNED) <= 8
+    graph._INTERNED.clear()

@@ -73,6 +73,20 @@ def _worker(rank, world, port, out_path):
         res["ref_flat"] = torch.cat([p.grad.reshape(-1) for p in reversed([q for q in ref.parameters() if q.requires_grad])])
         res["ref_stats"] = torch.cat([ref._inputNormalizer._E_data, ref._targetNormalizer._E_data_squared])
         res["ref_p0"] = next(ref.parameters()).detach().clone()
+    # Restore-then-warm-up (Trainer.restore with a checkpoint taken during warm-up): statistics every rank already
+    # shares (`base`) plus per-rank additions -> the merge counts the shared part ONCE.
+    nm = Normalizer(3)
+    gen2 = torch.Generator().manual_seed(11)
+    chunks = [torch.randn(50, 3, generator=gen2, dtype=torch.float64) * (k + 1) + k for k in range(3)]
+    nm._accumulate(chunks[0])                                   # "restored": identical on both ranks
+    base = nm.snapshot()
+    nm._accumulate(chunks[1 + rank])                            # warm-up continues on this rank's shard
+    nm.synchronize(None, base=base)
+    seq = Normalizer(3)
+    for c in chunks:
+        seq._accumulate(c)
+    res["base_merge"] = torch.cat([nm._acc_weight.data, nm._num_accumulations.data, nm._E_data.data, nm._E_data_squared.data])
+    res["base_seq"] = torch.cat([seq._acc_weight.data, seq._num_accumulations.data, seq._E_data.data, seq._E_data_squared.data])
     torch.save(res, f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
@@ -92,3 +106,5 @@ def test_two_rank_gradients_match_single_process(tmp_path):
     err = (r0["flat"] - r0["ref_flat"]).abs().max() / r0["ref_flat"].abs().max()
     assert err < 1e-5, err                                                                 # summed grads == big batch
     assert abs(float(r0["norm"]) - float(r0["ref_flat"].norm())) < 1e-4 * float(r0["ref_flat"].norm())
+    for r in (r0, r1):                                                                     # shared base counted once
+        torch.testing.assert_close(r["base_merge"], r["base_seq"], rtol=1e-12, atol=1e-15)

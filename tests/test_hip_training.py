@@ -202,3 +202,53 @@ def test_data_parallel_uses_the_fused_step(eng, graphs):
     dp.fused = None
     l_a = float(dp.step_loss_backward(data, True))
     assert abs(l_f - l_a) < 1e-6 * abs(l_a) and rel_err(g_f.cpu(), dp.grads.flat.cpu()) < 2e-6
+
+
+def test_fused_step_rejects_misshaped_batches_and_returns_fresh_losses(eng, graphs):
+    """FusedStep hands raw pointers with sizes from cfg to the C ABI: a batch that does not match cfg must raise before
+    any launch (the autograd path would fail with a PyTorch shape error).  Returned losses are copies, not views of the
+    static buffer the next step overwrites."""
+    cfg = ro.make_cfg(2, 32, 3, 3, 2)
+    data = _sim_batch(eng, graphs)
+    torch.manual_seed(4)
+    sim = eng.BSMS_Simulator(cfg).cuda()
+    sim(data, True, True)
+    step = eng.FusedStep(sim, eng.GradBuckets(list(sim.parameters())))
+    node_in, tar, mask, m_gs, m_ids = data
+    bad = [
+        (node_in[..., :-1], tar, mask, m_gs, m_ids),                      # a feature column short
+        (node_in, tar[..., :1], mask, m_gs, m_ids),                       # wrong out_dim
+        (node_in, tar[:, :-1], mask, m_gs, m_ids),                        # a node short
+        (node_in, tar, mask[:, :-1], m_gs, m_ids),                        # mask of another size
+        (node_in, tar, mask, m_gs[:-1], m_ids),                           # a level short
+        (node_in, tar.cpu(), mask, m_gs, m_ids),                          # mixed devices
+    ]
+    for d in bad:
+        with pytest.raises(RuntimeError):
+            step(d, True)
+    l1 = step(data, True)
+    v1 = float(l1)
+    l2 = step((node_in * 1.5, tar, mask, m_gs, m_ids), True)
+    assert float(l1) == v1 and float(l2) != v1                            # l1 survived the second step
+
+
+def test_inference_session_sees_raw_pointer_updates(eng, graphs):
+    """ops.InferenceSession reuses weight packs between forward-only calls; an optimizer step through the C ABI does not
+    bump the tensors' version counters, so the session keys on the engine's parameter epoch as well."""
+    from types import SimpleNamespace
+    from bsms_gnn_amd.ops import InferenceSession
+    cfg = ro.make_cfg(2, 32, 3, 3, 2)
+    data = _sim_batch(eng, graphs)
+    torch.manual_seed(6)
+    tr = eng.Trainer(eng.BSMS_Simulator(cfg), SimpleNamespace(consistent_mesh=True, accumulation_steps=1),
+                     SimpleNamespace(peak_lr=1e-2, weight_decay=1e-4, warmup_steps=1, decay_steps=20, gnorm_clip=1.0))
+    tr.iter(data)
+    node_in, tar, mask, m_gs, m_ids = data
+    gs, ids = [g[0] for g in m_gs], [i[0] for i in m_ids]
+    sess = InferenceSession(static_pos=True)
+    with torch.no_grad():
+        a = tr.model._infer(ids, gs, node_in, mask, session=sess).clone()
+        tr.iter(data); tr.iter(data)                                      # lr > 0 from the second optimizer step on
+        b = tr.model._infer(ids, gs, node_in, mask, session=sess).clone()
+        c = tr.model._infer(ids, gs, node_in, mask).clone()               # no session: packs rebuilt
+    assert torch.equal(b, c) and not torch.equal(a, b)
