@@ -11,21 +11,27 @@
 // registers between layers -- no LDS round trip, no HBM traffic.  LayerNorm over a row is 32 in-lane values + two
 // cross-group exchanges.
 //
-// Arithmetic: fp32 results from v_mfma_f32_16x16x32_bf16 by EXACT three-way splitting.  An fp32 value is the sum
-// of three bf16 numbers, x = hi + mid + lo (8 + 8 + 8 significand bits, by truncation: the split is exact), for
-// both operands; a product x*w is accumulated in fp32 as the six partial products whose weight is >= 2^-16,
-//          hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid);
-// the three dropped terms are <= 2^-24 |x w| each, the size of an fp32 rounding.  Measured against an fp64 product
-// the result is no worse than the f32 MFMA it replaces (rms 6e-8 vs 1.4e-7), at 16/6 = 2.7x its throughput
-// (v_mfma_f32_16x16x4_f32: 64 flop/cycle/SIMD, the bf16 form 1024).  Inputs, outputs, accumulation, LayerNorm and
-// everything stored to HBM stay fp32.
+// Arithmetic: fp32 results from v_mfma_f32_16x16x32_f16 by TWO-WAY fp16 splitting with power-of-two scaling.
+// A value is written as  x * 2^k = h + l,  h = fp16(x 2^k), l = fp16(x 2^k - h)  (round to nearest: 11 + 11 significand
+// bits, sign included in each piece); k is chosen per ROW of the activation tile (row maximum -> [2^12, 2^13), so h never
+// overflows and l stays a normal fp16 for every element within 2^15 of the row maximum) and per weight MATRIX.  A product
+// is accumulated in fp32 as the three partial products
+//          h_w * l_x  +  h_w * h_x  +  l_w * h_x;
+// the dropped l_w * l_x is <= 2^-22 |x w|, and the result is un-scaled by the exact power of two 2^-(k_x + k_w).
+// Measured against an fp64 product (profiles/census/f16split.hip, profiles/r03_f16split.md) this is MORE accurate than
+// the exact three-way bf16 split of rounds 1-2 (six products, truncated pieces), than v_mfma_f32_16x16x4_f32 and than a
+// sequential fp32 dot product, for activations, gradients of magnitude 1e-7, rows mixing 1e4 / 1 / 1e-6 and rows of 1e-30
+// or 1e30 alike -- at half the matrix instructions (3 instead of 6 per fragment pair), 2/3 of the weight bytes and 4
+// instead of 9-11 VALU operations per pair of elements (v_fma_mix{lo,hi}_f16 folds scaling, subtraction and rounding).
+// Inputs, outputs, accumulation, bias, LayerNorm and everything stored to HBM stay fp32.
 //
 // Weights are re-laid out once per call ("prepack") into chunks, one per 32-feature K block:
-//          [1 KB header: the Linear's bias (chunk 0 of a pack) or zeros]
-//          [t][plane hi|mid|lo][lane] 16 bytes = the 8 bf16 of A-fragment (t, kb2) for that lane
-// (25 KB per chunk at D = 128).  A LOADER wave streams chunks L2 -> LDS with LDS-DMA (global_load_lds_dwordx4, no
-// registers, two chunks in flight) through a 3-deep ring, one workgroup barrier per chunk; compute waves read
-// their A fragments with conflict-free lane-linear ds_read_b128.
+//          [1 KB header]  [t][plane h|l][lane] 16 bytes = the 8 fp16 of A-fragment (t, kb2) for that lane
+// (17 KB per chunk at D = 128).  Header of chunk 0: float 255 = 2^-k_w (the un-scaling factor of the matrix); header of
+// the LAST chunk: the Linear's bias (needed when the stage finishes).  A LOADER wave streams chunks L2 -> LDS with
+// LDS-DMA (global_load_lds_dwordx4, no registers, two chunks in flight) through a 3-deep ring, one workgroup barrier per
+// chunk; compute waves read their A fragments with conflict-free lane-linear ds_read_b128.
+// (The bf16 PRECISION of the edge MLP -- bsms_precision -- keeps one bf16 plane per weight and its bias in chunk 0.)
 #pragma once
 #include "common.h"
 
@@ -47,12 +53,13 @@ constexpr size_t mask_words_per_row(int64_t D) { return size_t(4) * (D <= 128 ? 
 // kPadRows rows, the edge kernels with two row blocks per wave): the stores then need no per-lane bounds test (rows
 // past R hold garbage nobody reads; the sign bits start after the padding and are padded the same way).
 constexpr int kPadRows = 2 * kTileRows;
-constexpr size_t pad_rows(size_t rows) { return (rows + kPadRows - 1) / kPadRows * kPadRows + kPadRows; }   // + one tile: tiles of 80..112 rows do not divide it
+constexpr size_t pad_rows(size_t rows) { return (rows + kPadRows - 1) / kPadRows * kPadRows + 2 * kPadRows; }   // + 256 rows: covers the last tile of any tile size up to 7 waves x 32 rows
 constexpr size_t act_floats(size_t rows, int64_t D) { return pad_rows(rows) * (size_t(D) + mask_words_per_row(D)); }
 // row pitch (floats) of the saved fiber tensor: p + 1 values padded to one or two 16-byte pieces
 constexpr int fiber_ld(int64_t p) { return p + 1 <= 4 ? 4 : 8; }
-// floats in one weight pack of a D x D Linear (bf16 x 3 planes + headers)
-constexpr size_t pack_floats(int64_t D) { return size_t(D / 32) * (kChunkHdrFloats + size_t(D / 16) * 768); }
+constexpr int kScaleSlot = 255;                          // header float of chunk 0 that holds 2^-k_w
+// floats in one weight pack of a D x D Linear (fp16 x 2 planes + headers)
+constexpr size_t pack_floats(int64_t D) { return size_t(D / 32) * (kChunkHdrFloats + size_t(D / 16) * 512); }
 
 enum ChainIn { IN_ROWS = 0, IN_ROWS2 = 1, IN_SMALL = 2, IN_EDGE = 3 };
 enum ChainOut { OUT_LN = 0, OUT_PLAIN = 1, OUT_SMALL = 2, OUT_PLAIN2 = 3 };  // PLAIN2: stage 0 -> y, stage 1 -> y2, same input
@@ -80,7 +87,7 @@ struct ChainFwdArgs {
   // ---- MFMA stages
   int nstage;
   const float4* wp[kMaxStages];  // packs (the Linear's bias travels in the pack header, see PackDesc)
-  const float4* wp0b;  // IN_ROWS2: pack for x2 in stage 0
+  const float4* wp0b;  // IN_ROWS2: pack for x2 in stage 0 (same scale as wp[0]: PackDesc::mate; the stage's bias rides in THIS pack)
   float* store[kMaxStages];  // post-ReLU activation of stage l, act_floats(R, D) floats: values + sign bits (nullable)
   // ---- output
   float* y;           // OUT_LN / OUT_PLAIN: [R,D]; OUT_SMALL: [R,C]
@@ -97,9 +104,14 @@ struct ChainFwdArgs {
   int bf16;           // bf16 precision (IN_EDGE / OUT_LN only): bf16 MFMA operands, saved activations and y stored as bf16
   int store_mode;     // saved-activation stores: 0 plain, 1 non-temporal (keeps L2 for weights / gathered rows)
   int out_mode;       // same for the final output y
-  // ---- filled by launch_chain_fwd: weight packs in execution order for the loader wave
+  // ---- filled by launch_chain_fwd: weight packs in execution order for the loader wave(s)
   int nseq;
   const float4* wseq[kMaxStages + 2];
+  int nload;          // loader waves per workgroup (the last `nload` waves of the block)
+  // ---- magnitude bounds for the weight-gradient kernel (wgrad.hip): bound slots (kBoundWidth floats each, see above)
+  // for the tensor ENTERING stage l -- amax[0]: x / [x, x2] / the activation of the narrow or edge input stage;
+  // amax[l + 1]: the post-ReLU activation of stage l.  Nullable.
+  float* amax[kMaxStages + 1];
 };
 
 struct ChainBwdArgs {
@@ -123,27 +135,39 @@ struct ChainBwdArgs {
   const float* dres;  // added to dx (residual branch), nullable
   int store_mode;     // layer-gradient stores: 0 plain, 1 non-temporal
   int bf16;           // bf16 precision (G_EDGE_LN / F_NONE only): yln is bf16, layer gradients are stored as bf16
-  // ---- filled by launch_chain_bwd: weight packs in execution order for the loader wave
+  // ---- filled by launch_chain_bwd: weight packs in execution order for the loader wave(s)
   int nseq;
   const float4* wseq[kMaxStages + 2];
+  int nload;          // loader waves per workgroup (the last `nload` waves of the block)
+  float* gmax[kMaxStages + 1];   // like ChainFwdArgs::amax for gstore[k] (the gradient entering stage k; [nstage]: the last one). Nullable.
 };
 
 // prepack table ---------------------------------------------------------------------------------
 enum PackKind { PACK_FRAG = 0, PACK_FRAG_T = 1, PACK_TRANSPOSE = 2 };
 struct PackDesc {
   const float* W;  // row-major, leading dimension ld
-  const float* bias;  // FRAG kinds: [N] copied into the header of chunk 0 (nullable -> zeros)
+  const float* bias;  // FRAG kinds: [N] copied into the header of the last chunk (bf16: of chunk 0); nullable -> zeros
   float* dst;      // FRAG kinds: pack_floats(N) floats
   int ld, row0, col0;
   int N, K;  // logical matrix M[n][k], n < N (outputs), k < K (reduction)
   int kind;  // FRAG: M[n][k] = W[row0+n][col0+k]; FRAG_T: M[n][k] = W[row0+k][col0+n];   (N == K, multiple of 32)
              // TRANSPOSE: dst[k*N+n] = W[row0+n][col0+k] (plain, for the small VALU layers)
-  int bf16;  // FRAG kinds: plane 0 = the weight rounded to bf16, planes 1 / 2 empty (bf16 precision)
+  int bf16;  // FRAG kinds: ONE plane = the weight rounded to bf16 (bf16 precision)
+  int mate;  // FRAG kinds, fp32 path: 1 + index of a pack of the same table that must share this pack's scale 2^k_w (the two
+             // halves of a Linear over concatenated inputs accumulate into one set of registers); 0 = none
 };
 constexpr int kMaxPack = 40;
+// Magnitude bounds of the tensors the weight-gradient kernel multiplies (ChainFwdArgs::amax, ChainBwdArgs::gmax,
+// WgradJob::g_bound).  A bound "slot" is an array of kBoundWidth floats: every compute wave of a chain launch writes the
+// largest |value| it saw into its own entry (blockIdx * 8 + wave; plain stores, no atomics: same-address atomics from
+// ~10^5 waves cost milliseconds), the consumer takes the maximum over the whole array (unused entries are zero: the
+// prepack of the forward call clears all slots of a block).
+constexpr int kBoundWidth = 4096;  // >= 8 x the largest chain grid (2 workgroups per CU)
+constexpr int kBoundSlots = 32;    // slots of one GMP block / MLP
 struct PackTable {
   int n;
   PackDesc d[kMaxPack];
+  float* zero;   // nullable: kBoundSlots x kBoundWidth floats the prepack sets to zero
 };
 int launch_prepack(const PackTable& t, hipStream_t s);
 
@@ -158,7 +182,13 @@ struct WgradJob {
   float* db;       // db[n] = sum_r G[r][n]   (nullable)
   int64_t R;
   int ldg, lda, ldw, col0;
-  int bf16;        // G and A are bf16 tensors (ld in elements): one bf16 product instead of the six split products
+  int bf16;        // G and A are bf16 tensors (ld in elements): one bf16 product instead of the split products
+  // Magnitude bounds of the two operands (bound slots written by the chain kernels, ChainFwdArgs::amax / ChainBwdArgs::gmax;
+  // bound = max(slot[0 .. kBoundWidth)) * mul >= max |value|).  Both given: the products run as fp16 x 2 pieces with per-TENSOR power-of-two
+  // scales (chain.h; the reduction index is the row, so a scale cannot vary by row) -- three MFMAs per fragment pair.
+  // Either missing: the exact three-way bf16 split of rounds 1-2 (six MFMAs), which needs no range information.
+  const float *g_bound, *a_bound;
+  float g_mul, a_mul;
 };
 constexpr int kMaxWgradJobs = 20;
 size_t wgrad_work_bytes(int D, int njobs);

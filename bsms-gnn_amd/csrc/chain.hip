@@ -6,6 +6,7 @@ using namespace bsms;
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kPL = 2;   // fp16 planes per weight of the fp32 path (chain.h); the bf16 precision has one
 
 // Register layout ("chain layout", see chain.h): a wave owns 16 rows; lane l <-> row (l & 15), group g = l >> 4.
 // For every 16-feature block t the lane holds features 16 t + 4 g + {0,1,2,3} as one f32x4.
@@ -43,7 +44,26 @@ __device__ __forceinline__ void store_rows_bf16(const f32x4 (&v)[NB], void* base
 }
 
 // ---------------------------------------------------------------------------------- prepack ----
-// exact three-way bf16 split by truncation: x = hi + mid + lo, each piece's low 16 bits are zero
+// fp32 -> two fp16 pieces of s * x (s a power of two; chain.h), two elements at a time: dword h = the hi pieces, dword l
+// the lo pieces, element 0 in the low half.  v_fma_mix{lo,hi}_f16 computes fma(a, b, c) from fp32 / fp16 sources with ONE
+// rounding to fp16: h = fp16(x s), l = fp16(x s - h) -- scaling, subtraction and rounding in one operation per piece.
+__device__ __forceinline__ void split_h2(float x0, float x1, float s, unsigned& h, unsigned& l) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+}
+
+// Power-of-two scale of a row / matrix with maximum magnitude `amax` (>= 0): biased exponent E of amax, clamped so that
+// s = 2^(139 - E) is a normal float; amax * s lies in [2^12, 2^13).  (E = 255: inf / nan rows propagate as such.)
+struct RowScale { float s; int E; };
+__device__ __forceinline__ RowScale scale_of(float amax, int emin = 12) {
+  int E = int(__float_as_uint(amax) >> 23);
+  E = E < emin ? emin : E;
+  return RowScale{__uint_as_float(unsigned(266 - E) << 23), E};
+}
+
+// exact three-way bf16 split by truncation (rounds 1-2; still the arithmetic of the weight-gradient kernel, wgrad.hip)
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
   hi = __float_as_uint(x) & 0xffff0000u;
   const float r1 = x - __uint_as_float(hi);
@@ -51,10 +71,43 @@ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, uns
   lo = __float_as_uint(r1 - __uint_as_float(mid));  // <= 8 significant bits left: already a bf16
 }
 
-// FRAG packs (layout in chain.h): per 32-feature K block c a chunk of kChunkHdrFloats + NB*768 dwords;
-//   body dword ((t*3 + plane)*64 + lane)*4 + v  =  bf16 pair (slots 2v, 2v+1) of plane `plane` of
+// FRAG packs (layout in chain.h): per 32-feature K block c a chunk of kChunkHdrFloats + NB * 256 * planes dwords;
+//   body dword ((t*planes + plane)*64 + lane)*4 + v  =  16-bit pair (slots 2v, 2v+1) of plane `plane` of
 //   M[16 t + (lane & 15)][16 (2c + (i >> 2)) + 4 (lane >> 4) + (i & 3)],  i = slot
-// with M[n][k] = W[row0+n][col0+k] (FRAG) or W[row0+k][col0+n] (FRAG_T).
+// with M[n][k] = W[row0+n][col0+k] (FRAG) or W[row0+k][col0+n] (FRAG_T).  fp32 path: planes = {h, l} of M * 2^k_w with
+// k_w from the largest |M| of this matrix (and of its mate); bf16 precision: one plane, the rounded weight.
+__device__ __forceinline__ float pack_elem(const PackDesc& d, int n, int k) {
+  return (d.kind == PACK_FRAG_T) ? d.W[int64_t(d.row0 + k) * d.ld + d.col0 + n] : d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
+}
+// pass 1 (one block per pack): 2^-k_w from the largest |M| of the matrix and of its mate -> header float kScaleSlot of
+// chunk 0, where pass 2 and the chain kernels read it
+__global__ __launch_bounds__(256) void k_pack_scale(PackTable tab) {
+  if (tab.zero)   // clear the block's bound slots (chain.h: kBoundWidth), spread over the launch
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < kBoundSlots * kBoundWidth / 4; o += gridDim.x * 256)
+      reinterpret_cast<float4*>(tab.zero)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const PackDesc d = tab.d[blockIdx.x];
+  if (d.kind == PACK_TRANSPOSE || d.bf16) return;
+  __shared__ float red[256];
+  float m = 0.f;
+  auto scan = [&](const PackDesc& e) {   // coalesced along the rows of W whatever the logical orientation
+    const int rows = (e.kind == PACK_FRAG_T) ? e.K : e.N, cols = (e.kind == PACK_FRAG_T) ? e.N : e.K;
+    for (int o = threadIdx.x; o < rows * cols; o += 256) m = fmaxf(m, fabsf(e.W[int64_t(e.row0 + o / cols) * e.ld + e.col0 + o % cols]));
+  };
+  scan(d);
+  if (d.mate) scan(tab.d[d.mate - 1]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (int(threadIdx.x) < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int Ew = int(__float_as_uint(red[0]) >> 23);
+    Ew = Ew < 13 ? 13 : (Ew > 254 ? 254 : Ew);            // 2^(139 - Ew) and its inverse are normal floats
+    d.dst[kScaleSlot] = __uint_as_float(unsigned(Ew - 12) << 23);    // 2^(Ew - 139) = 2^-k_w
+  }
+}
+
 __global__ __launch_bounds__(256) void k_prepack(PackTable tab) {
   const PackDesc d = tab.d[blockIdx.y];
   if (d.kind == PACK_TRANSPOSE) {
@@ -65,34 +118,35 @@ __global__ __launch_bounds__(256) void k_prepack(PackTable tab) {
     }
     return;
   }
-  const int nb = d.N >> 4, planes = d.bf16 ? 1 : 3, chf = kChunkHdrFloats + nb * 256 * planes;   // bf16 precision: one plane
-  const int total = (d.K >> 5) * chf;
+  float sw = 1.f;
+  if (!d.bf16) sw = __uint_as_float(unsigned(254 - int(__float_as_uint(d.dst[kScaleSlot]) >> 23)) << 23);   // 2^k_w = 1 / header value
+  const int nb = d.N >> 4, planes = d.bf16 ? 1 : kPL, chf = kChunkHdrFloats + nb * 256 * planes, nch = d.K >> 5;
+  const int total = nch * chf;
   unsigned* dst = reinterpret_cast<unsigned*>(d.dst);
   for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
     const int c = o / chf, w = o % chf;
     if (w < kChunkHdrFloats) {
-      d.dst[o] = (c == 0 && d.bias && w < d.N) ? d.bias[w] : 0.f;
+      float v = 0.f;
+      if (d.bf16) {
+        if (c == 0 && d.bias && w < d.N) v = d.bias[w];
+      } else {
+        if (c == nch - 1 && d.bias && w < d.N) v = d.bias[w];
+        if (c == 0 && w == kScaleSlot) continue;          // written by k_pack_scale (nch == 1 means N = 32: no clash with the bias)
+      }
+      d.dst[o] = v;
       continue;
     }
     const int q = w - kChunkHdrFloats;
     const int v = q & 3, lane = (q >> 2) & 63, tp = q >> 8, plane = tp % planes, t = tp / planes;
-    unsigned piece[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int i = 2 * v + e;
-      const int n = 16 * t + (lane & 15), k = 16 * (2 * c + (i >> 2)) + 4 * (lane >> 4) + (i & 3);
-      const float x = (d.kind == PACK_FRAG_T) ? d.W[int64_t(d.row0 + k) * d.ld + d.col0 + n]
-                                              : d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
-      unsigned hi, mid, lo;
-      if (d.bf16) {   // bf16 precision: the weight IS its bf16 rounding (nearest even); planes 1 and 2 stay empty
-        hi = pk_bf16(x, 0.f) << 16;
-        mid = lo = 0u;
-      } else {
-        split3(x, hi, mid, lo);
-      }
-      piece[e] = plane == 0 ? hi : plane == 1 ? mid : lo;
+    const int n = 16 * t + (lane & 15), k = 16 * (2 * c + ((2 * v) >> 2)) + 4 * (lane >> 4) + ((2 * v) & 3);   // slots 2v, 2v + 1
+    const float x0 = pack_elem(d, n, k), x1 = pack_elem(d, n, k + 1);
+    if (d.bf16) {   // bf16 precision: the weight IS its bf16 rounding (nearest even)
+      dst[o] = pk_bf16(x0, x1);
+    } else {
+      unsigned h, l;
+      split_h2(x0, x1, sw, h, l);
+      dst[o] = plane == 0 ? h : l;
     }
-    dst[o] = (piece[0] >> 16) | (piece[1] & 0xffff0000u);
   }
 }
 
@@ -224,7 +278,7 @@ __device__ __forceinline__ float row_sum(const f32x4 (&v)[NB]) {
 
 // ---------------------------------------------------------------------------- weight streaming
 // Workgroup = 4 compute waves + 1 LOADER wave.  The loader streams the weight packs of all stages of every tile of
-// this workgroup, chunk by chunk (a chunk = 32 input features x all outputs x 3 bf16 planes + header, 25 KB at
+// this workgroup, chunk by chunk (a chunk = 32 input features x all outputs x 2 fp16 planes + header, 17 KB at
 // D = 128), from L2 into a 3-deep LDS ring with LDS-DMA: no registers, two chunks in flight, a counted
 // s_waitcnt vmcnt before it publishes a chunk at the workgroup barrier.  One barrier per chunk.
 //
@@ -233,8 +287,8 @@ __device__ __forceinline__ float row_sum(const f32x4 (&v)[NB]) {
 // until its activation stores had reached memory -- MFMA phases and HBM phases then add up instead of
 // overlapping (measured: kernel time = MFMA time + store time).  Compute waves execute NO vmcnt wait in the
 // steady state; their stores drain in the background.
-// PL: bf16 planes per weight (3 = the exact fp32 split; 1 = the bf16 precision, whose packs carry the rounded weight only)
-template <int NB, int PL = 3>
+// PL: 16-bit planes per weight (2 = the fp32 path's fp16 pieces h, l; 1 = the bf16 precision, whose packs carry the rounded weight only)
+template <int NB, int PL = kPL>
 struct Ring {
   static constexpr int D = NB * 16;
   static constexpr int NCH = NB / 2;                          // chunks per stage (one per 32-feature K block)
@@ -243,7 +297,8 @@ struct Ring {
   static constexpr int PER = CHF / 256;                       // LDS-DMA instructions (1 KB each) per chunk
   static constexpr int NR = 3;                                // ring depth
   static constexpr int SIDE_FLOATS = 8 * D;                   // side table after the ring: the edge MLP's fiber weights
-  static constexpr size_t lds_bytes = size_t(NR) * CHF * sizeof(float) + SIDE_FLOATS * sizeof(float);
+  static constexpr int BOUND_WORDS = 8 * 16;                  // after the side table: running magnitude bounds, 16 stages x 8 waves
+  static constexpr size_t lds_bytes = size_t(NR) * CHF * sizeof(float) + SIDE_FLOATS * sizeof(float) + BOUND_WORDS * sizeof(unsigned);
   static_assert(CHF % 256 == 0 && PER < 64, "chunk = whole LDS-DMA instructions, countable by vmcnt");
   static_assert(NB % 2 == 0, "K blocks are pairs of 16-feature blocks");
 };
@@ -259,22 +314,28 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// the loader wave's whole life
-template <int NB, int PL = 3>
+template <int NB, int PL = kPL>
 __device__ __forceinline__ float* ring_side(float4* lds) { return reinterpret_cast<float*>(lds + Ring<NB, PL>::NR * Ring<NB, PL>::CH4); }
 
 // `side` (nullable, 8*D floats in HBM): copied once into the side table; the compute waves wait for it at one extra
 // barrier before their first tile.
-template <int NB, int PL = 3>
+// NL loader waves share a chunk piece by piece (wave LI issues pieces LI, LI + NL, ...): one wave's LDS-DMA rate is its
+// own ISSUE rate (~60 cycles per 1 KB piece alone, 100-185 beside a busy compute wave of its SIMD;
+// profiles/census/ldsdma_rate.hip: 39 / 61 / 87 GB/s per CU with 1 / 2 / 4 loader waves), and since the fp32 products
+// take three MFMAs per fragment pair instead of six the weight stream, not the matrix pipe, paces a stage.
+template <int NB, int PL, int NL, int LI>
 __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles,
                                            const float* side = nullptr) {
   using R = Ring<NB, PL>;
+  constexpr int MINE = (R::PER - LI + NL - 1) / NL;   // pieces of a chunk this wave issues
   __builtin_amdgcn_s_setprio(3);                   // the loader must never be the wave the others wait for
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
   if (side) {
-    const unsigned dst = lds0 + unsigned(R::NR) * unsigned(R::CHF * sizeof(float));
+    if (LI == 0) {
+      const unsigned dst = lds0 + unsigned(R::NR) * unsigned(R::CHF * sizeof(float));
 #pragma unroll
-    for (int i = 0; i < R::SIDE_FLOATS / 256; ++i) glds16(reinterpret_cast<const float4*>(side) + i * 64 + lane, dst + i * 1024);
+      for (int i = 0; i < R::SIDE_FLOATS / 256; ++i) glds16(reinterpret_cast<const float4*>(side) + i * 64 + lane, dst + i * 1024);
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
   const int my_tiles = (ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
@@ -284,7 +345,7 @@ __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, 
     const float4* src = wseq[is] + size_t(ic) * R::CH4 + lane;
     const unsigned dst = lds0 + unsigned(islot) * unsigned(R::CHF * sizeof(float));
 #pragma unroll
-    for (int i = 0; i < R::PER; ++i) glds16(src + i * 64, dst + i * 1024);
+    for (int i = 0; i < MINE; ++i) glds16(src + (LI + i * NL) * 64, dst + (LI + i * NL) * 1024);
     if (++ic == R::NCH) { ic = 0; if (++is == nseq) is = 0; }
     if (++islot == R::NR) islot = 0;
   };
@@ -292,34 +353,36 @@ __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, 
   if (total > 1) issue();
   for (int j = 0; j < total; ++j) {
     // chunk j has landed once at most the (whole) younger chunk is still outstanding
-    if (j + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R::PER) : "memory");
+    if (j + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");       // barrier #j: publishes chunk j; everyone is done with chunk j-1,
     if (j + 2 < total) issue();                    // whose slot chunk j+2 now overwrites
   }
 }
+// loader wave `li` of `nl` (1..3)
+template <int NB, int PL = kPL>
+__device__ __forceinline__ void loader_dispatch(int nl, int li, const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles,
+                                                const float* side = nullptr) {
+  if (nl == 1) loader_run<NB, PL, 1, 0>(wseq, nseq, lds, lane, ntiles, side);
+  else if (nl == 2) { if (li == 0) loader_run<NB, PL, 2, 0>(wseq, nseq, lds, lane, ntiles, side); else loader_run<NB, PL, 2, 1>(wseq, nseq, lds, lane, ntiles, side); }
+  else { if (li == 0) loader_run<NB, PL, 3, 0>(wseq, nseq, lds, lane, ntiles, side); else if (li == 1) loader_run<NB, PL, 3, 1>(wseq, nseq, lds, lane, ntiles, side);
+         else loader_run<NB, PL, 3, 2>(wseq, nseq, lds, lane, ntiles, side); }
+}
 
-// bf16 pieces of one lane's activations as B operands: plane[kb2] = 8 bf16 = slots i of K block kb2 (chain.h)
+// 16-bit pieces of one lane's activations as B operands: plane[kb2] = 8 values = slots i of K block kb2 (chain.h)
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
-// planes of K block kb2 (features 32 kb2 .. +31 of this lane's row)
+// fp16 pieces {h, l} of s * (K block kb2 = features 32 kb2 .. +31 of this lane's row)
 template <int NB>
-__device__ __forceinline__ void split_block(const f32x4 (&act)[NB], int kb2, u32x4& bh, u32x4& bm, u32x4& bl) {
-  using f2 = __attribute__((ext_vector_type(2))) float;
-  using u2 = __attribute__((ext_vector_type(2))) unsigned;
+__device__ __forceinline__ void split_block(const f32x4 (&act)[NB], int kb2, float s, u32x4& bh, u32x4& bl) {
 #pragma unroll
   for (int v = 0; v < 4; ++v) {  // dword v = slots 2v, 2v+1 = act[2 kb2 + (v >> 1)][2 (v & 1) + {0, 1}]
-    // the same exact split as split3, two elements at a time: the residuals are packed subtractions (v_pk_add_f32),
-    // 9 VALU operations per pair instead of 11 -- the chain kernels are bound by the SIMD's issue port
-    const f2 x = {act[2 * kb2 + (v >> 1)][2 * (v & 1)], act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1]};
-    const u2 h = __builtin_bit_cast(u2, x) & 0xffff0000u;
-    const f2 r1 = x - __builtin_bit_cast(f2, h);
-    const u2 m = __builtin_bit_cast(u2, r1) & 0xffff0000u;
-    const u2 l = __builtin_bit_cast(u2, r1 - __builtin_bit_cast(f2, m));
-    bh[v] = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u);
-    bm[v] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
-    bl[v] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+    unsigned h, l;
+    split_h2(act[2 * kb2 + (v >> 1)][2 * (v & 1)], act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1], s, h, l);
+    bh[v] = h;
+    bl[v] = l;
   }
 }
 
@@ -330,76 +393,152 @@ __device__ __forceinline__ void round_block(const f32x4 (&act)[NB], int kb2, u32
   for (int v = 0; v < 4; ++v) bh[v] = pk_bf16(act[2 * kb2 + (v >> 1)][2 * (v & 1)], act[2 * kb2 + (v >> 1)][2 * (v & 1) + 1]);
 }
 
-__device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
+__device__ __forceinline__ f32x4 mma_bf(const float4& a, const u32x4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mma(const float4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
-// One Linear on the compute waves: acc[t] (+)= sum_k W[16t + ., k] * act[k] with the six bf16 partial products.
-// `slot` = ring slot of the stage's first chunk (advanced here).  `from_header`: start acc from the bias in the
-// header of the stage's first chunk instead of accumulating onto the caller's acc.
-// `store_base` (nullable, uniform) + `store_off`: HBM tensor / this lane's row offset that receives `act`; issued
-// right after the split so the store has the whole stage to drain.  All compute waves of the workgroup must call this together.
-// BF (bf16 precision, chain.h): operands are the bf16 roundings of `act` and of the weights (plane 0 of the pack holds
-// the rounded weight, the other planes are unused), ONE product per fragment pair; `store_base` receives bf16 rows.
-template <int NB, bool TIMED = false, bool BF = false>
-__device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
-                                           bool from_header, float* store_base = nullptr, int64_t store_off = -1,
-                                           int store_mode = 0, int64_t mask_rows = 0,
-                                           unsigned long long* waited = nullptr, int64_t row = 0, int64_t nrows = 0) {
-  if constexpr (BF) {
-    using R = Ring<NB, 1>;
-    u32x4 bb[NB / 2];
-    round_block<NB>(act, 0, bb[0]);
-    const bool st = store_base != nullptr && store_off >= 0;
+// largest |value| of this lane's row (all four lane groups)
+template <int NB>
+__device__ __forceinline__ float row_amax(const f32x4 (&v)[NB]) {
+  float m = 0.f;
 #pragma unroll
-    for (int c = 0; c < R::NCH; ++c) {
-      lds_barrier();
-      const float4* cur = lds + slot * R::CH4;
-      if (++slot == R::NR) slot = 0;
-      if (c == 0 && from_header) {
-        const float* bl_ = reinterpret_cast<const float*>(cur);
+  for (int t = 0; t < NB; ++t) {
+    m = fmaxf(fmaxf(m, fabsf(v[t][0])), fabsf(v[t][1]));   // v_max3_f32 with |.| modifiers
+    m = fmaxf(fmaxf(m, fabsf(v[t][2])), fabsf(v[t][3]));
+  }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  return fmaxf(m, __shfl_xor(m, 32, 64));
+}
+
+// Running magnitude bounds (chain.h: kBoundWidth).  Every compute wave keeps, per stage, the largest |value| of the rows
+// it has processed in a private row of 16 LDS words (no other wave touches it: no synchronisation); after its last tile
+// it writes them to its entry of the bound slots.  `m` is a row maximum (>= 0, the same in the four lanes of a row): max
+// over the wave's 16 rows with DPP, then one lane updates the LDS word.  Bit patterns of non-negative floats order like
+// integers (inf / nan rows publish inf / nan: the consumer's results are then inf / nan too, as in the reference).
+template <int NB, int PL = kPL>
+__device__ __forceinline__ unsigned* bound_row(float4* lds, int wave, int lane) {
+  unsigned* row = reinterpret_cast<unsigned*>(ring_side<NB, PL>(lds) + Ring<NB, PL>::SIDE_FLOATS) + wave * 16;
+  if (lane < 16) row[lane] = 0u;
+  return row;
+}
+__device__ __forceinline__ void note_amax(unsigned* brow, int stage, float m, int lane) {
+  int v = __float_as_int(m);
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));   // row_shr:2
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));   // row_shr:1
+  if (lane == 15) brow[stage] = max(brow[stage], unsigned(v));
+}
+__device__ __forceinline__ void flush_bounds(float* const* slots, int n, const unsigned* brow, int wave, int lane) {
+  const int entry = int(blockIdx.x) * 8 + wave;
+  for (int k = 0; k < n; ++k)   // uniform
+    if (slots[k] && lane == 0 && entry < kBoundWidth) slots[k][entry] = __uint_as_float(brow[k]);
+}
+
+// End of a stage: the accumulators hold sum (s_w W)(s_x x); un-scale by the exact power of two 2^-(k_x + k_w) and add
+// the bias (header of the stage's last chunk, still in the ring: its slot is not overwritten before every compute wave
+// has passed the next chunk barrier).  `fw` = exponent field of 2^-k_w (header of chunk 0), E = the row's (RowScale).
+// The combined factor is a normal float unless a row or a matrix is tiny or huge beyond ~2^+-60: that (wave-uniform)
+// case takes v_ldexp_f32, which is exact over the whole range.
+template <int NB, bool BIAS>
+__device__ __forceinline__ void finish_stage(f32x4 (&acc)[NB], int E, int fw, const float* hdr, int lane) {
+  const int f = E + fw - 139;   // exponent field of 2^-(k_x + k_w) = 2^(E - 139) 2^(fw - 127)
+  const float* hb = hdr + 4 * (lane >> 4);
+  if (__builtin_amdgcn_ballot_w64(unsigned(f - 1) >= 254u) == 0) {
+    const float inv = __uint_as_float(unsigned(f) << 23);
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-          const float4 x = *reinterpret_cast<const float4*>(bl_ + 16 * t + 4 * (lane >> 4));
-          acc[t] = f32x4{x.x, x.y, x.z, x.w};
-        }
-      }
-      if (st) {   // two 16-feature blocks of the saved activation per chunk, spread over the stage like the fp32 pairs
-        store_block_bf16<NB>(act, store_base, store_off / (NB * 16), lane >> 4, 2 * c);
-        store_block_bf16<NB>(act, store_base, store_off / (NB * 16), lane >> 4, 2 * c + 1);
-      }
-      const float4* body = cur + kChunkHdrFloats / 4 + lane;
-#pragma unroll
-      for (int t = 0; t < NB; t += 2) {
-        const float4 h0 = body[t * 64], h1 = body[(t + 1) * 64];   // one plane per pack
-        acc[t] = mma(h0, bb[c], acc[t]);
-        acc[t + 1] = mma(h1, bb[c], acc[t + 1]);
-        if (t == 0) {
-          if (c + 1 < R::NCH) round_block<NB>(act, c + 1, bb[c + 1]);
-          else if (mask_rows) store_mask_bits<NB, true>(act, store_base, mask_rows, store_off, lane >> 4);
-        }
+    for (int t = 0; t < NB; ++t) {
+      if (BIAS) {
+        const float4 x = *reinterpret_cast<const float4*>(hb + 16 * t);
+        acc[t] = f32x4{fmaf(acc[t][0], inv, x.x), fmaf(acc[t][1], inv, x.y), fmaf(acc[t][2], inv, x.z), fmaf(acc[t][3], inv, x.w)};
+      } else {
+        acc[t] *= inv;
       }
     }
-    return;
+  } else {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BIAS) x = *reinterpret_cast<const float4*>(hb + 16 * t);
+      acc[t] = f32x4{ldexpf(acc[t][0], f - 127) + x.x, ldexpf(acc[t][1], f - 127) + x.y, ldexpf(acc[t][2], f - 127) + x.z,
+                     ldexpf(acc[t][3], f - 127) + x.w};
+    }
   }
+}
+
+// bf16 precision (chain.h): operands are the bf16 roundings of `act` and of the weights (one plane per pack, bias in the
+// header of chunk 0), ONE product per fragment pair; `store_base` receives bf16 rows.
+template <int NB>
+__device__ __forceinline__ void mfma_stage_bf(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
+                                              bool from_header, float* store_base, int64_t store_off, int64_t mask_rows) {
+  using R = Ring<NB, 1>;
+  u32x4 bb[NB / 2];
+  round_block<NB>(act, 0, bb[0]);
+  const bool st = store_base != nullptr && store_off >= 0;
+#pragma unroll
+  for (int c = 0; c < R::NCH; ++c) {
+    lds_barrier();
+    const float4* cur = lds + slot * R::CH4;
+    if (++slot == R::NR) slot = 0;
+    if (c == 0 && from_header) {
+      const float* bl_ = reinterpret_cast<const float*>(cur);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const float4 x = *reinterpret_cast<const float4*>(bl_ + 16 * t + 4 * (lane >> 4));
+        acc[t] = f32x4{x.x, x.y, x.z, x.w};
+      }
+    }
+    if (st) {   // two 16-feature blocks of the saved activation per chunk, spread over the stage like the fp32 pairs
+      store_block_bf16<NB>(act, store_base, store_off / (NB * 16), lane >> 4, 2 * c);
+      store_block_bf16<NB>(act, store_base, store_off / (NB * 16), lane >> 4, 2 * c + 1);
+    }
+    const float4* body = cur + kChunkHdrFloats / 4 + lane;
+#pragma unroll
+    for (int t = 0; t < NB; t += 2) {
+      const float4 h0 = body[t * 64], h1 = body[(t + 1) * 64];   // one plane per pack
+      acc[t] = mma_bf(h0, bb[c], acc[t]);
+      acc[t + 1] = mma_bf(h1, bb[c], acc[t + 1]);
+      if (t == 0) {
+        if (c + 1 < R::NCH) round_block<NB>(act, c + 1, bb[c + 1]);
+        else if (mask_rows) store_mask_bits<NB, true>(act, store_base, mask_rows, store_off, lane >> 4);
+      }
+    }
+  }
+}
+
+// One Linear on the compute waves (fp32 path): the three fp16 partial products per fragment pair, chain.h.
+//   ZERO: the accumulators start from zero (else: they continue a sum begun by the previous call with the SAME row scale
+//         and a pack of the same weight scale -- the two halves of a Linear over concatenated inputs, PackDesc::mate)
+//   FIN:  0 leave the raw scaled sums (the next call continues them), 1 un-scale, 2 un-scale and add the pack's bias
+// `slot` = ring slot of the stage's first chunk (advanced here).  `rs`: scale of this lane's row (scale_of(row_amax)).
+// `store_base` (nullable, uniform) + `row` / `nrows`: HBM tensor that receives `act` as streaming 128-byte pairs, one
+// pair per chunk, + its ReLU sign bits when `mask_rows`.  All compute waves of the workgroup must call this together.
+template <int NB, bool ZERO, int FIN, bool TIMED = false>
+__device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], const RowScale rs, float4* lds, int& slot,
+                                           int lane, float* store_base = nullptr, int64_t store_off = -1,
+                                           int store_mode = 0, int64_t mask_rows = 0,
+                                           unsigned long long* waited = nullptr, int64_t row = 0, int64_t nrows = 0) {
   using R = Ring<NB>;
-  // The per-element VALU work of a stage (three-way split, sign bits) is spread over the chunks instead of sitting
-  // in front of the first MFMA: only K block 0 is split up front, block c + 1 is split in the shadow of chunk c's
-  // MFMAs (an MFMA occupies the issue port for 4 of its 16 cycles).
-  u32x4 bh[NB / 2], bm[NB / 2], bl[NB / 2];
-  split_block<NB>(act, 0, bh[0], bm[0], bl[0]);
+  // The per-element VALU work of a stage (two-way split, sign bits) is spread over the chunks instead of sitting in
+  // front of the first MFMA: only K block 0 is split up front, block c + 1 is split in the shadow of chunk c's MFMAs.
+  u32x4 bh[NB / 2], bl[NB / 2];
+  split_block<NB>(act, 0, rs.s, bh[0], bl[0]);
 #ifdef BSMS_EXPERIMENTS
   const bool paired = (store_mode == 1 || store_mode == 2) && nrows > 0;   // saved tensors: 128-byte pieces, one pair per chunk
   const bool streaming = store_mode == 1;
   if (!paired) store_rows<NB, false>(act, store_base, store_off, lane >> 4, store_mode);
 #else
   // production: a saved tensor is always written as streaming 128-byte pairs (callers pass nrows > 0 with every
-  // store_base); the store-mode switches exist in experiment builds only -- as run-time flags they put three variants
-  // of every store and their scalar branches into the hot loop
+  // store_base); the store-mode switches exist in experiment builds only
   constexpr bool paired = true, streaming = true;
   (void)store_mode;
   if (nrows <= 0) store_base = nullptr;
 #endif
+  int fw = 0;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     if (TIMED) {   // experiments: cycles this wave spends waiting at the chunk barriers
@@ -411,46 +550,30 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
     }
     const float4* cur = lds + slot * R::CH4;
     if (++slot == R::NR) slot = 0;
-    if (c == 0 && from_header) {
-      const float* bl_ = reinterpret_cast<const float*>(cur);
-#pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        const float4 x = *reinterpret_cast<const float4*>(bl_ + 16 * t + 4 * (lane >> 4));
-        acc[t] = f32x4{x.x, x.y, x.z, x.w};
-      }
-    }
+    if (c == 0) fw = int(__float_as_uint(reinterpret_cast<const float*>(cur)[kScaleSlot]) >> 23);
     if (paired) store_pair_stream<NB>(act, store_base, row, nrows, lane, 2 * c, streaming);
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
-    // two accumulators interleaved so that back-to-back MFMAs are independent; one weight plane at a time (each
-    // fragment pair is dead after its products: 8 fragment registers live + the next pair in flight)
+    // two accumulators interleaved so that back-to-back MFMAs are independent; one weight plane at a time
 #pragma unroll
     for (int t = 0; t < NB; t += 2) {
       {
-        const float4 h0 = body[(t * 3 + 0) * 64], h1 = body[(t * 3 + 3) * 64];
-        acc[t] = mma(h0, bl[c], acc[t]);
-        acc[t + 1] = mma(h1, bl[c], acc[t + 1]);
-        acc[t] = mma(h0, bm[c], acc[t]);
-        acc[t + 1] = mma(h1, bm[c], acc[t + 1]);
+        const float4 h0 = body[(t * 2 + 0) * 64], h1 = body[(t * 2 + 2) * 64];
+        acc[t] = mma(h0, bl[c], (ZERO && c == 0) ? zero : acc[t]);
+        acc[t + 1] = mma(h1, bl[c], (ZERO && c == 0) ? zero : acc[t + 1]);
         acc[t] = mma(h0, bh[c], acc[t]);
         acc[t + 1] = mma(h1, bh[c], acc[t + 1]);
       }
       if (t == 0) {   // VALU work for later, placed among this chunk's MFMAs
-        if (c + 1 < R::NCH) split_block<NB>(act, c + 1, bh[c + 1], bm[c + 1], bl[c + 1]);
+        if (c + 1 < R::NCH) split_block<NB>(act, c + 1, rs.s, bh[c + 1], bl[c + 1]);
         else if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);  // saved activation: + sign bits
       }
       {
-        const float4 m0 = body[(t * 3 + 1) * 64], m1 = body[(t * 3 + 4) * 64];
-        acc[t] = mma(m0, bm[c], acc[t]);
-        acc[t + 1] = mma(m1, bm[c], acc[t + 1]);
-        acc[t] = mma(m0, bh[c], acc[t]);
-        acc[t + 1] = mma(m1, bh[c], acc[t + 1]);
-      }
-      {
-        const float4 l0 = body[(t * 3 + 2) * 64], l1 = body[(t * 3 + 5) * 64];
+        const float4 l0 = body[(t * 2 + 1) * 64], l1 = body[(t * 2 + 3) * 64];
         acc[t] = mma(l0, bh[c], acc[t]);
         acc[t + 1] = mma(l1, bh[c], acc[t + 1]);
       }
     }
+    if (FIN != 0 && c == R::NCH - 1) finish_stage<NB, FIN == 2>(acc, rs.E, fw, reinterpret_cast<const float*>(cur), lane);
   }
 }
 
@@ -497,9 +620,9 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  const int cw = int(blockDim.x >> 6) - 1;   // compute waves of this launch (4..7, chosen by the launcher); the last wave loads
-  if (wave == cw) {  // loader wave (uniform branch)
-    loader_run<NB, BF ? 1 : 3>(a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
+  const int cw = int(blockDim.x >> 6) - a.nload;   // compute waves of this launch (4..7, chosen by the launcher); the last wave(s) load
+  if (wave >= cw) {  // loader wave (uniform branch)
+    loader_dispatch<NB, BF ? 1 : kPL>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
     return;
   }
   // IN_EDGE: the fiber weights are read from the LDS side table (read from HBM/L2 they cost one dependent round
@@ -507,9 +630,10 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   const float* w0t = a.w0t;
   if (IN == IN_EDGE) {
     lds_barrier();
-    w0t = ring_side<NB, BF ? 1 : 3>(lds);
+    w0t = ring_side<NB, BF ? 1 : kPL>(lds);
   }
   int slot = 0;  // ring slot of the next chunk; runs on across this workgroup's tiles exactly like the loader's
+  unsigned* brow = bound_row<NB, BF ? 1 : kPL>(lds, wave, lane);   // this wave's running magnitude bounds
   // Persistent workgroups: the grid is sized to what the chip holds at once and strides over the tiles, so a CU
   // never waits for the dispatcher to refill a slot (measured: 20-35 % of slot time was empty with one
   // workgroup per tile) and the loader is already fetching the next tile's first chunk during this epilogue.
@@ -590,21 +714,38 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     store_mask_bits<NB>(act, pending, a.R, roff, lg);
   }
   if (OUT == OUT_PLAIN2) {  // two Linears of the SAME rows (the edge MLP's two node projections): one launch, one read of x
-    mfma_stage<NB>(acc, act, lds, slot, lane, true);
+    const float m = row_amax<NB>(act);
+    note_amax(brow, 0, m, lane);
+    const RowScale rs = scale_of(m);
+    mfma_stage<NB, true, 2>(acc, act, rs, lds, slot, lane);
     store_rows<NB, false>(acc, a.y, roff, lg);
-    mfma_stage<NB>(acc, act, lds, slot, lane, true);
+    mfma_stage<NB, true, 2>(acc, act, rs, lds, slot, lane);
     store_rows<NB, false>(acc, a.y2, roff, lg);
     continue;
   }
   for (int l = 0; l < a.nstage; ++l) {
-    mfma_stage<NB, TIMING, BF>(acc, act, lds, slot, lane, true, pending, roff, a.store_mode & 3, (a.store_mode & 4) ? 0 : a.R, &waited,
-                               row, (a.store_mode & 8) ? 0 : a.R);  // acc = bias + W act
+    if constexpr (BF) {
+      mfma_stage_bf<NB>(acc, act, lds, slot, lane, true, pending, roff, (a.store_mode & 4) ? 0 : a.R);   // acc = bias + W act
+    } else if (IN == IN_ROWS2 && l == 0) {
+      // Linear over the concatenation [x, x2]: ONE row scale (the larger of the two rows' maxima; the second source is
+      // read once more for it -- node-level rows, L2-resident) and one weight scale (PackDesc::mate), so the second half
+      // continues the raw sums of the first; the bias rides in the second pack
+      float m = row_amax<NB>(act);
+      load_rows<NB>(acc, a.x2 + rowc * D, lg);
+      m = fmaxf(m, row_amax<NB>(acc));
+      note_amax(brow, 0, m, lane);
+      const RowScale rs = scale_of(m);
+      mfma_stage<NB, true, 0>(acc, act, rs, lds, slot, lane);
+      load_rows<NB>(act, a.x2 + rowc * D, lg);
+      mfma_stage<NB, false, 2>(acc, act, rs, lds, slot, lane);
+    } else {
+      const float m = row_amax<NB>(act);
+      note_amax(brow, l, m, lane);
+      mfma_stage<NB, true, 2, TIMING>(acc, act, scale_of(m), lds, slot, lane, pending, roff, a.store_mode & 3,
+                                      (a.store_mode & 4) ? 0 : a.R, &waited, row, (a.store_mode & 8) ? 0 : a.R);  // acc = bias + W act
+    }
     stamp();          // stage l done
     pending = nullptr;
-    if (IN == IN_ROWS2 && l == 0) {
-      load_rows<NB>(act, a.x2 + rowc * D, lg);
-      mfma_stage<NB>(acc, act, lds, slot, lane, false);
-    }
     const bool last = (l == a.nstage - 1);
     if (!last || OUT == OUT_SMALL) {
       relu_into<NB>(act, acc);
@@ -668,6 +809,7 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     }
   }
   }  // tile loop
+  flush_bounds(a.amax, kMaxStages + 1, brow, wave, lane);
 }
 
 // ------------------------------------------------------------------------------- backward chain
@@ -688,12 +830,13 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  const int cw = int(blockDim.x >> 6) - 1;   // compute waves of this launch (4..7, chosen by the launcher); the last wave loads
-  if (wave == cw) {  // loader wave (uniform branch)
-    loader_run<NB, BF ? 1 : 3>(a.wseq, a.nseq, lds, lane, a.ntiles);
+  const int cw = int(blockDim.x >> 6) - a.nload;   // compute waves of this launch (4..7, chosen by the launcher); the last wave(s) load
+  if (wave >= cw) {  // loader wave (uniform branch)
+    loader_dispatch<NB, BF ? 1 : kPL>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles);
     return;
   }
   int slot = 0;  // ring slot of the next chunk, across this workgroup's tiles
+  unsigned* brow = bound_row<NB, BF ? 1 : kPL>(lds, wave, lane);   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {  // persistent workgroups (see k_chain_fwd)
   const int64_t row = int64_t(tile) * (16 * cw) + wave * 16 + (lane & 15);
   const bool live = row < a.R;
@@ -743,8 +886,15 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     for (int w = 0; w < mask_words<NB>(); ++w)
       mbits[w] = a.mask[k] ? reinterpret_cast<const unsigned*>(a.mask[k] + (BF ? pad_rows(a.R) * D / 2 : pad_rows(a.R) * D))[rowc * (4 * mask_words<NB>()) + lg * mask_words<NB>() + w]
                            : 0xffffffffu;
-    zero_tile<NB>(acc);
-    mfma_stage<NB, false, BF>(acc, g, lds, slot, lane, false, pending, roff, a.store_mode & 3, 0, nullptr, row, (a.store_mode & 8) ? 0 : a.R);
+    if constexpr (BF) {
+      zero_tile<NB>(acc);
+      mfma_stage_bf<NB>(acc, g, lds, slot, lane, false, pending, roff, 0);
+    } else {
+      const float m = row_amax<NB>(g);
+      note_amax(brow, k, m, lane);
+      mfma_stage<NB, true, 1>(acc, g, scale_of(m), lds, slot, lane, pending, roff, a.store_mode & 3, 0, nullptr, row,
+                              (a.store_mode & 8) ? 0 : a.R);
+    }
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
@@ -756,8 +906,10 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   }
 
   if (FIRST != F_NONE) {
-    zero_tile<NB>(acc);
-    mfma_stage<NB>(acc, g, lds, slot, lane, false, pending, roff, 1, 0, nullptr, row, a.R);
+    const float mh = row_amax<NB>(g);
+    note_amax(brow, a.nstage, mh, lane);
+    const RowScale rs = scale_of(mh);
+    mfma_stage<NB, true, 1>(acc, g, rs, lds, slot, lane, pending, roff, 1, 0, nullptr, row, a.R);
     pending = nullptr;
     if (a.dres) {
       f32x4 r[NB];
@@ -767,17 +919,18 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     }
     if (FIRST == F_HEADS2) {
       f32x4 acc2[NB];
-      zero_tile<NB>(acc2);
-      mfma_stage<NB>(acc2, g, lds, slot, lane, false);
+      mfma_stage<NB, true, 1>(acc2, g, rs, lds, slot, lane);
       store_rows<NB, false>(acc, a.dx, roff, lg);
       store_rows<NB, false>(acc2, a.dx2, roff, lg);
     } else {
       store_rows<NB, false>(acc, a.dx, roff, lg);
     }
   }
+  if (FIRST == F_NONE && a.gmax[a.nstage]) note_amax(brow, a.nstage, row_amax<NB>(g), lane);   // uniform
   if constexpr (BF) store_rows_bf16<NB>(g, pending, roff, lg);
   else store_rows<NB, false>(g, pending, roff, lg);
   }  // tile loop
+  flush_bounds(a.gmax, kMaxStages + 1, brow, wave, lane);
 }
 
 // store_pair_stream for the pipelined edge kernels: the tensor is non-null and padded (no tests), and the per-lane
@@ -807,42 +960,30 @@ __device__ __forceinline__ void store_pair_nt(const f32x4 (&v)[NB], float* base,
 }
 
 // ------------------------------------------------------------- edge MLP chains, software-pipelined ----
-// The edge MLP (IN_EDGE / OUT_LN forward, G_EDGE_LN / F_NONE backward) is 45 % of the training step.  In k_chain_fwd /
+// The edge MLP (IN_EDGE / OUT_LN forward, G_EDGE_LN / F_NONE backward) is ~45 % of the training step.  In k_chain_fwd /
 // k_chain_bwd every A-fragment pair is read from LDS right before its MFMAs (the 128-VGPR budget of two workgroups
-// per CU leaves no room to prefetch), so an in-order wave exposes one LDS round trip per 4 MFMAs and two waves per
-// SIMD hide only part of each other's stalls: the kernels run at ~55 % of their MFMA time (profiles/tile_timeline.py).
-// Here a wave owns RB row blocks of 16 rows: ONE fragment pair feeds 2 RB x {6, 4, 2} MFMAs, the next pair is in
+// per CU leaves no room to prefetch), so an in-order wave exposes one LDS round trip per pair.
+// Here a wave owns RB row blocks of 16 rows: ONE fragment pair feeds 2 RB x {2, 1} MFMAs, the next pair is in
 // flight while they run, 2 RB independent accumulator chains interleave (no dependent back-to-back MFMAs), and the
 // workgroup barrier + bias reads are paid once per RB x 64 rows.  RB = 2 at D = 128 (one workgroup per CU, 256-VGPR
 // budget), RB = 1 at D = 256 (the 32 + 32 blocks of one row block already fill the budget).
-// The arithmetic (order of the six partial products per accumulator) is exactly mfma_stage's: results are bit-identical.
-// The VALU work of a stage, cut into STEPS of 3-6 operations that are placed by hand between the MFMA pairs of the
+// The arithmetic (order of the three partial products per accumulator, chain.h) is exactly mfma_stage's: bit-identical.
+// The VALU work of a stage, cut into STEPS of 2-4 operations that are placed by hand between the MFMA pairs of the
 // chunk before the one that needs them (sched_barrier fences keep hipcc from regrouping them: left alone it emits the
-// split of a K block as one lump of ~45 VALU operations during which the matrix pipe drains, and its IGroupLP
-// pipelines (sched_group_barrier) either explode in compile time or silently skip some regions).  Per row block:
+// split of a K block as one lump during which the matrix pipe drains, and its IGroupLP pipelines (sched_group_barrier)
+// either explode in compile time or silently skip some regions).  Per row block:
 //   P0..P3  streaming store of feature blocks 2c, 2c + 1 of the activation: DPP exchange (2 steps), select + store (2)
-//   S0..S11 exact three-way bf16 split of K block c + 1: per dword (two features) {hi, residual}, {mid, lo}, {3 packs}
-//   M0..M11 (last chunk of a saved activation instead of S) ReLU sign bits, then the store of the words
-struct Pieces { unsigned h[4], m[4], l[4]; };
-__device__ __forceinline__ float sub_nopk(float a, float b) {   // a - b that the SLP vectoriser cannot pack
-  float d;
-  asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
+//   S0..S7  fp16 pieces of K block c + 1: per dword (two features) {h}, {l}  (two v_fma_mix each)
+//   M0..M7  (last chunk of a saved activation instead of S) ReLU sign bits, then the store of the words
+struct Pieces { unsigned h[4], l[4]; };
 __device__ __forceinline__ u32x4 vec4(const unsigned (&d)[4]) { return u32x4{d[0], d[1], d[2], d[3]}; }
-struct StepState {
-  __attribute__((ext_vector_type(2))) unsigned hh, m;
-  __attribute__((ext_vector_type(2))) float r1, l;
-  int got[4];
-};
+struct StepState { int got[4]; };
 
 template <int NB, int RB, bool SAVE, bool MASK>
 __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][NB], Pieces (&pc)[RB][2], StepState (&st)[RB],
-                                          unsigned (&mword)[RB][mask_words<NB>()], float* store_base, unsigned* bits_base,
-                                          const PairOff (&off)[RB], const unsigned (&moff)[RB], int lane) {
-  using f2 = __attribute__((ext_vector_type(2))) float;
-  using u2 = __attribute__((ext_vector_type(2))) unsigned;
-  constexpr int W = mask_words<NB>(), NP = SAVE ? 4 : 0, PER = NP + 12;
+                                          const RowScale (&rs)[RB], unsigned (&mword)[RB][mask_words<NB>()], float* store_base,
+                                          unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB], int lane) {
+  constexpr int W = mask_words<NB>(), NP = SAVE ? 4 : 0, PER = NP + 8;
   const int rb = s / PER, q = s % PER;
   if (rb >= RB) return;
   const bool last = c + 1 == Ring<NB>::NCH;
@@ -870,34 +1011,25 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
   }
   const int ss = q - NP;
   if (!last) {    // ---- S steps: K block c + 1 -> pc[rb][(c + 1) & 1]
-    const int v = ss / 3, ph = ss % 3, kb2 = c + 1;
+    const int v = ss >> 1, kb2 = c + 1;
     Pieces& o = pc[rb][kb2 & 1];
-    if (ph == 0) {
-      const f2 x = {act[rb][2 * kb2 + (v >> 1)][2 * (v & 1)], act[rb][2 * kb2 + (v >> 1)][2 * (v & 1) + 1]};
-      st[rb].hh = __builtin_bit_cast(u2, x) & 0xffff0000u;
-      // two scalar subtractions, not one v_pk_add_f32: beside MFMAs a packed fp32 operation costs ~13 cycles more than
-      // the two it replaces (MI355X_MICROARCH.md, price of fillers)
-      st[rb].r1[0] = sub_nopk(x[0], __uint_as_float(st[rb].hh[0]));
-      st[rb].r1[1] = sub_nopk(x[1], __uint_as_float(st[rb].hh[1]));
-    } else if (ph == 1) {
-      st[rb].m = __builtin_bit_cast(u2, st[rb].r1) & 0xffff0000u;
-      st[rb].l[0] = sub_nopk(st[rb].r1[0], __uint_as_float(st[rb].m[0]));
-      st[rb].l[1] = sub_nopk(st[rb].r1[1], __uint_as_float(st[rb].m[1]));
+    const float x0 = act[rb][2 * kb2 + (v >> 1)][2 * (v & 1)], x1 = act[rb][2 * kb2 + (v >> 1)][2 * (v & 1) + 1];
+    if ((ss & 1) == 0) {
+      asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(o.h[v]) : "v"(x0), "v"(rs[rb].s));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(o.h[v]) : "v"(x1), "v"(rs[rb].s));
     } else {
-      const u2 l = __builtin_bit_cast(u2, st[rb].l);
-      o.h[v] = __builtin_amdgcn_perm(st[rb].hh[1], st[rb].hh[0], 0x07060302u);
-      o.m[v] = __builtin_amdgcn_perm(st[rb].m[1], st[rb].m[0], 0x07060302u);
-      o.l[v] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+      asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(o.l[v]) : "v"(x0), "v"(rs[rb].s), "v"(o.h[v]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(o.l[v]) : "v"(x1), "v"(rs[rb].s), "v"(o.h[v]));
     }
   } else if (SAVE && MASK) {   // ---- M steps
-    constexpr int EPS = (4 * NB + 11) / 12;
+    constexpr int EPS = (4 * NB + 7) / 8;
 #pragma unroll
     for (int e = ss * EPS; e < (ss + 1) * EPS && e < 4 * NB; ++e) {
       unsigned b;
       asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(act[rb][e >> 2][e & 3])));   // post-ReLU value: positive iff non-zero bits
       mword[rb][e >> 5] |= b << (e & 31);
     }
-    if (ss == 11) {
+    if (ss == 7) {
       unsigned* bits = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(bits_base) + moff[rb]);
 #pragma unroll
       for (int w = 0; w < W; ++w) bits[w] = mword[rb][w];   // rows past R land in the padding (chain.h: act_floats)
@@ -905,87 +1037,76 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
   }
 }
 
+// HDR: acc = bias + W act (forward); else acc = W act (backward).  The accumulators start from zero either way.
 template <int NB, int RB, bool SAVE, bool MASK, bool HDR>
 __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, int& slot, int lane,
-                                         float* store_base, unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB]) {
+                                         float* store_base, unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB],
+                                         unsigned* brow, int stage) {
   using Rg = Ring<NB>;
   constexpr int W = mask_words<NB>();
-  constexpr int NSLOT = (NB / 2) * 6 * RB;            // MFMA pairs per chunk
-  constexpr int NSTEP = RB * ((SAVE ? 4 : 0) + 12);   // VALU steps per chunk
+  constexpr int NSLOT = (NB / 2) * 3 * RB;            // MFMA pairs per chunk
+  constexpr int NSTEP = RB * ((SAVE ? 4 : 0) + 8);    // VALU steps per chunk
   static_assert(NSTEP <= NSLOT, "at most one step per MFMA pair");
-  Pieces pc[RB][2];                                   // split pieces of K blocks c (slot c & 1) and c + 1
+  Pieces pc[RB][2];                                   // pieces of K blocks c (slot c & 1) and c + 1
   StepState st[RB];
+  RowScale rs[RB];
   unsigned mword[RB][W];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    u32x4 h, m, l;
-    split_block<NB>(act[rb], 0, h, m, l);
+    const float m = row_amax<NB>(act[rb]);
+    note_amax(brow, stage, m, lane);
+    rs[rb] = scale_of(m);
+    u32x4 h, l;
+    split_block<NB>(act[rb], 0, rs[rb].s, h, l);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) { pc[rb][0].h[v] = h[v]; pc[rb][0].m[v] = m[v]; pc[rb][0].l[v] = l[v]; }
+    for (int v = 0; v < 4; ++v) { pc[rb][0].h[v] = h[v]; pc[rb][0].l[v] = l[v]; }
 #pragma unroll
     for (int w = 0; w < W; ++w) mword[rb][w] = 0;
   }
+  int fw = 0;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < Rg::NCH; ++c) {
     lds_barrier();                                         // chunk has landed (and my reads of the last one are done)
     const float4* cur = lds + slot * Rg::CH4;
     if (++slot == Rg::NR) slot = 0;
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
-    float4 f0 = body[0], f1 = body[3 * 64];                // pair (t = 0, plane hi)
-    if (c == 0) {
-      if (HDR) {
-        const float* hdr = reinterpret_cast<const float*>(cur);
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-          const float4 x = *reinterpret_cast<const float4*>(hdr + 16 * t + 4 * (lane >> 4));
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) acc[rb][t] = f32x4{x.x, x.y, x.z, x.w};
-        }
-      } else {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) zero_tile<NB>(acc[rb]);
-      }
-    }
+    float4 f0 = body[0], f1 = body[2 * 64];                // pair (t = 0, plane h)
+    if (c == 0) fw = int(__float_as_uint(reinterpret_cast<const float*>(cur)[kScaleSlot]) >> 23);
     const int cb = c & 1;
     int islot = 0;   // MFMA pair within the chunk
     // one MFMA pair (feature blocks t, t + 1 of row block rb, one plane combination), then the VALU step that rides with it
-    auto pair = [&](int t, int rb, const float4& a0, const float4& a1, const unsigned (&piece)[4]) {
-      acc[rb][t] = mma(a0, vec4(piece), acc[rb][t]);
-      acc[rb][t + 1] = mma(a1, vec4(piece), acc[rb][t + 1]);
+    auto pair = [&](int t, int rb, const float4& a0, const float4& a1, const unsigned (&piece)[4], bool first) {
+      acc[rb][t] = mma(a0, vec4(piece), (first && c == 0) ? zero : acc[rb][t]);
+      acc[rb][t + 1] = mma(a1, vec4(piece), (first && c == 0) ? zero : acc[rb][t + 1]);
       const int s = (islot * NSTEP + NSLOT - 1) / NSLOT;          // the step whose place is this pair, if any
       if (s < NSTEP && s * NSLOT / NSTEP == islot)
-        valu_step<NB, RB, SAVE, MASK>(s, c, act, pc, st, mword, store_base, bits_base, off, moff, lane);
+        valu_step<NB, RB, SAVE, MASK>(s, c, act, pc, st, rs, mword, store_base, bits_base, off, moff, lane);
       ++islot;
       __builtin_amdgcn_sched_barrier(0);
     };
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NB; t += 2) {
-      float4 n0 = body[(t * 3 + 1) * 64], n1 = body[(t * 3 + 4) * 64];          // plane mid of (t, t + 1): one pair ahead
+      float4 n0 = body[(t * 2 + 1) * 64], n1 = body[(t * 2 + 3) * 64];          // plane l of (t, t + 1): one pair ahead
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].l);
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].l, true);
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].m);
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h);
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h, false);
       f0 = n0;
       f1 = n1;
-      n0 = body[(t * 3 + 2) * 64];                                                // plane lo
-      n1 = body[(t * 3 + 5) * 64];
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].m);
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h);
-      f0 = n0;
-      f1 = n1;
-      if (t + 2 < NB) {                                                           // plane hi of the next block pair
-        n0 = body[((t + 2) * 3) * 64];
-        n1 = body[((t + 2) * 3 + 3) * 64];
+      if (t + 2 < NB) {                                                           // plane h of the next block pair
+        n0 = body[((t + 2) * 2) * 64];
+        n1 = body[((t + 2) * 2 + 2) * 64];
       }
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h);
+      for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h, false);
       f0 = n0;
       f1 = n1;
+    }
+    if (c == Rg::NCH - 1) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) finish_stage<NB, HDR>(acc[rb], rs[rb].E, fw, reinterpret_cast<const float*>(cur), lane);
     }
   }
 }
@@ -1014,9 +1135,9 @@ void k_edge_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  const int cw = int(blockDim.x >> 6) - 1, tile_rows = 16 * RB * cw;   // compute waves of this launch (launcher's choice); the last wave loads
-  if (wave == cw) {  // loader wave (uniform branch)
-    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles, a.w0t);
+  const int cw = int(blockDim.x >> 6) - a.nload, tile_rows = 16 * RB * cw;   // compute waves of this launch (launcher's choice); the last wave(s) load
+  if (wave >= cw) {  // loader wave (uniform branch)
+    loader_dispatch<NB>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles, a.w0t);
     return;
   }
   const float rcpE = 1.f / float(a.E);
@@ -1037,6 +1158,7 @@ void k_edge_fwd(ChainFwdArgs a) {
   lds_barrier();
   const float* w0t = ring_side<NB>(lds);   // fiber weights (LDS side table, see k_chain_fwd)
   int slot = 0;
+  unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int64_t row[RB];
     PairOff off[RB];
@@ -1109,7 +1231,7 @@ void k_edge_fwd(ChainFwdArgs a) {
     for (int l = 0; l < a.nstage; ++l) {
       float* st_tile = SAVE ? pending + int64_t(tile) * (tile_rows * D) : nullptr;   // uniform
       unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (tile_rows * 4 * mask_words<NB>()) : nullptr;
-      stage_rb<NB, RB, SAVE, true, true>(acc, act, lds, slot, lane, st_tile, bits_tile, off, moff);   // acc = bias + W act
+      stage_rb<NB, RB, SAVE, true, true>(acc, act, lds, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
       stamp();
       if (l + 1 < a.nstage) {
 #pragma unroll
@@ -1142,6 +1264,7 @@ void k_edge_fwd(ChainFwdArgs a) {
     }
     stamp();
   }
+  if (SAVE) flush_bounds(a.amax, kMaxStages + 1, brow, wave, lane);
 }
 
 template <int NB, int RB>
@@ -1150,9 +1273,9 @@ void k_edge_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16, W = mask_words<NB>();
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
-  const int cw = int(blockDim.x >> 6) - 1, tile_rows = 16 * RB * cw;   // compute waves of this launch (launcher's choice); the last wave loads
-  if (wave == cw) {  // loader wave (uniform branch)
-    loader_run<NB>(a.wseq, a.nseq, lds, lane, a.ntiles);
+  const int cw = int(blockDim.x >> 6) - a.nload, tile_rows = 16 * RB * cw;   // compute waves of this launch (launcher's choice); the last wave(s) load
+  if (wave >= cw) {  // loader wave (uniform branch)
+    loader_dispatch<NB>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles);
     return;
   }
   const float rcpE = 1.f / float(a.E);
@@ -1167,6 +1290,7 @@ void k_edge_bwd(ChainBwdArgs a) {
   int64_t nnode[RB];
   fetch_targets(blockIdx.x, nnode);
   int slot = 0;
+  unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int64_t row[RB], rowc[RB];
     PairOff off[RB];
@@ -1208,7 +1332,7 @@ void k_edge_bwd(ChainBwdArgs a) {
 #pragma unroll
         for (int w = 0; w < W; ++w)
           mbits[rb][w] = reinterpret_cast<const unsigned*>(a.mask[k] + pad_rows(a.R) * D)[rowc[rb] * (4 * W) + lg * W + w];
-      stage_rb<NB, RB, true, false, false>(acc, g, lds, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff);
+      stage_rb<NB, RB, true, false, false>(acc, g, lds, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff, brow, k);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -1221,9 +1345,12 @@ void k_edge_bwd(ChainBwdArgs a) {
       pending = a.gstore[k + 1];
     }
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)   // gE[0]: read next by the scatter kernel, plain stores (stay in L2 / the memory-side cache)
+    for (int rb = 0; rb < RB; ++rb) {  // gE[0]: read next by the scatter kernel, plain stores (stay in L2 / the memory-side cache)
+      if (a.gmax[a.nstage]) note_amax(brow, a.nstage, row_amax<NB>(g[rb]), lane);   // uniform
       store_rows<NB, false>(g[rb], pending, row[rb] < a.R ? row[rb] * D : -1, lg);
+    }
   }
+  flush_bounds(a.gmax, kMaxStages + 1, brow, wave, lane);
 }
 
 // Workgroups of 5 waves the chip keeps resident per CU at each width.  NOT the occupancy API's answer: the SPI
@@ -1276,6 +1403,18 @@ inline int device_cus() {
   return cus;
 }
 
+// Launch shape knobs.  Production values are the defaults; experiment builds read them from the environment for
+// same-box sweeps (BSMS_EDGE_CW, BSMS_EDGE_NL, BSMS_CHAIN_NL, BSMS_EDGE_CW16, BSMS_EDGE_NL16).
+inline int knob(const char* name, int dflt) {
+#ifdef BSMS_EXPERIMENTS
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
+
 // experiment builds (same-box A/B, profiles/edge_prof.sh): BSMS_EDGE_RB = 0 keeps the edge MLP on k_chain_fwd / k_chain_bwd,
 // 1 / 2 force the number of row blocks per wave
 inline int edge_rb_mode() {
@@ -1292,12 +1431,18 @@ inline int edge_rb_mode() {
 // per CU, 8 waves = two per SIMD at the 256-VGPR budget) spread that stream over 1.75x the rows.  At D = 128 stream
 // and compute are level and larger tiles measured +-0 (profiles/r02_edge_levels.md): 4.
 template <int NB>
-constexpr int edge_compute_waves() {
-#ifdef BSMS_EDGE16_CW
-  return NB >= 16 ? BSMS_EDGE16_CW : kComputeWaves;
-#else
-  return NB >= 16 ? 7 : kComputeWaves;
-#endif
+int edge_compute_waves() {
+  static const int cw = NB >= 16 ? knob("BSMS_EDGE_CW16", 7) : knob("BSMS_EDGE_CW", kComputeWaves);
+  return cw;
+}
+template <int NB>
+int edge_loader_waves() {
+  static const int nl = NB >= 16 ? knob("BSMS_EDGE_NL16", 1) : knob("BSMS_EDGE_NL", 1);
+  return nl;
+}
+inline int chain_loader_waves() {
+  static const int nl = knob("BSMS_CHAIN_NL", 1);
+  return nl;
 }
 
 template <int NB, int RB, bool SAVE>
@@ -1305,10 +1450,11 @@ int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes);
-  constexpr int cw = edge_compute_waves<NB>();
+  const int cw = edge_compute_waves<NB>();
+  a.nload = edge_loader_waves<NB>();
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
-  hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE>), dim3(grid), dim3((cw + 1) * 64), Ring<NB>::lds_bytes, s, a);
+  hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -1338,10 +1484,11 @@ int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes);
-  constexpr int cw = edge_compute_waves<NB>();
+  const int cw = edge_compute_waves<NB>();
+  a.nload = edge_loader_waves<NB>();
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
-  hipLaunchKernelGGL((k_edge_bwd<NB, RB>), dim3(grid), dim3((cw + 1) * 64), Ring<NB>::lds_bytes, s, a);
+  hipLaunchKernelGGL((k_edge_bwd<NB, RB>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -1375,7 +1522,8 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
     if (launch_edge_fwd<NB>(a, s, rc)) return rc;
   }
   const int cw = (IN == IN_EDGE) ? kComputeWaves : chain_compute_waves<NB>(a.R);
-  const dim3 threads((cw + 1) * 64);
+  a.nload = std::min(chain_loader_waves(), 8 - cw);
+  const dim3 threads((cw + a.nload) * 64);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
   bool launched = false;
   if constexpr (NB == 8 && IN == IN_EDGE) {   // the only instantiation with stamps
@@ -1431,7 +1579,8 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", lds);
   const int cw = (GIN == G_EDGE_LN) ? kComputeWaves : chain_compute_waves<NB>(a.R);
-  const dim3 threads((cw + 1) * 64);
+  a.nload = std::min(chain_loader_waves(), 8 - cw);
+  const dim3 threads((cw + a.nload) * 64);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
   if constexpr ((NB == 8 || NB == 16) && GIN == G_EDGE_LN && FIRST == F_NONE) {
     int rc = BSMS_OK;
@@ -1484,6 +1633,8 @@ int launch_prepack(const PackTable& t, hipStream_t s) {
   int biggest = 0;
   for (int i = 0; i < t.n; ++i) biggest = biggest > t.d[i].N * t.d[i].K ? biggest : t.d[i].N * t.d[i].K;
   const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(biggest, 256), 64);
+  hipLaunchKernelGGL(k_pack_scale, dim3(t.n), dim3(256), 0, s, t);
+  BSMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_prepack, dim3(gx, t.n), dim3(256), 0, s, t);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;

@@ -92,6 +92,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 struct bsms_plan {
   int64_t N = 0, E = 0, Nk = 0;
   int64_t min_out_degree = 0, max_source = -1;
+  int64_t max_in_degree = 0, max_out_degree = 0;   // bound the scatter sums of a bounded tensor (wgrad.hip: operand scales)
   int32_t *rowptr = nullptr, *src = nullptr, *dst = nullptr, *perm = nullptr;
   int32_t *t_rowptr = nullptr, *t_dst = nullptr, *t_eid = nullptr, *t_pos = nullptr;
   int32_t *ids = nullptr, *inv = nullptr;

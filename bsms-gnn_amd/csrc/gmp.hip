@@ -63,6 +63,10 @@ struct GmpSaved {
   // packs (fragment order)
   float *e_wi, *e_wj, *e_wft, *e_w[kMaxStages], *e_wt[kMaxStages], *e_wit, *e_wjt;
   float *n_w0x, *n_w0a, *n_w[kMaxStages], *n_wt[kMaxStages], *n_w0xt, *n_w0at;
+  // magnitude bounds (training; chain.h: kBoundSlots floats, zeroed by the block's prepack): [0..7] tensor entering edge
+  // forward stage l (e_act[l]); [8..15] node forward stage l ([8]: x and aggr jointly, [8 + l]: n_act[l - 1]);
+  // [16..23] gradient entering edge backward stage k (gE[H - k]; [16 + H]: gE[0]); [24..31] node backward (gN[H - k])
+  float* bound;
   size_t bytes;
 };
 // training = true: everything the backward needs.  training = false (inference, `saved` == NULL at the ABI):
@@ -86,6 +90,7 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
     for (int l = 0; l < H; ++l) s.n_act[l] = c.take(act_floats(rn, D));
     s.n_yln = c.take(rn * D);
     s.n_rstd = c.take(rn);
+    s.bound = c.take(size_t(kBoundSlots) * kBoundWidth);
   }
   Carver cp(packs_base);
   Carver& k = packs_base ? cp : c;
@@ -169,17 +174,22 @@ int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training
   add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG, sv.e_wi, pe[1]);
   add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG, sv.e_wj);
   add_pack(t, pe[0], ldE0, 0, 0, (int)D, int(p + 1), PACK_TRANSPOSE, sv.e_wft);
-  if (training) {
+  if (training) {   // grad_x += dPs Wi + dPd Wj runs as ONE Linear over [dPs, dPd]: the two packs share their scale (chain.h: mate)
     add_pack(t, pe[0], ldE0, 0, int(p + 1), (int)D, (int)D, PACK_FRAG_T, sv.e_wit);
     add_pack(t, pe[0], ldE0, 0, int(p + 1 + D), (int)D, (int)D, PACK_FRAG_T, sv.e_wjt);
+    t.d[t.n - 2].mate = t.n;        // 1 + index of the other
+    t.d[t.n - 1].mate = t.n - 1;
   }
   for (int l = 1; l <= H; ++l) {   // the D x D Linears of the edge MLP: bf16 operands in the bf16 precision
     add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.e_w[l], pe[2 * l + 1]);
     t.d[t.n - 1].bf16 = bf;
     if (training) { add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]); t.d[t.n - 1].bf16 = bf; }
   }
-  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x, pn[1]);
-  add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG, sv.n_w0a);
+  // first node Linear over [x, aggr]: two packs, one scale; the bias rides in the second one (where the stage finishes)
+  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x);
+  add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG, sv.n_w0a, pn[1]);
+  t.d[t.n - 2].mate = t.n;
+  t.d[t.n - 1].mate = t.n - 1;
   if (training) {
     add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_w0xt);
     add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG_T, sv.n_w0at);
@@ -188,6 +198,7 @@ int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training
     add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w[l], pn[2 * l + 1]);
     if (training) add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_wt[l]);
   }
+  t.zero = training ? sv.bound : nullptr;
   return launch_prepack(t, s);
 }
 }  // namespace
@@ -250,6 +261,7 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       a.store[st] = (training && st < H - 1) ? sv.e_act[st + 1] : nullptr;
     }
     a.y = sv.e_y; a.rstd = sv.e_rstd;
+    if (training && !bf) for (int st = 0; st < H; ++st) a.amax[st] = sv.bound + size_t(st) * kBoundWidth;
     a.timing = g_timing;
     a.store_mode = ((g_debug_flags & 2) ? 0 : 1) | ((g_debug_flags & 64) ? 4 : 0) | ((g_debug_flags & 128) ? 8 : 0);   // non-temporal stores (experiments: +4 no sign bits, +8 unpaired 64-byte pieces)
     a.out_mode = (g_debug_flags & 4) ? 1 : 0;
@@ -273,6 +285,7 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       a.store[st] = (training && st < H) ? sv.n_act[st] : nullptr;
     }
     a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x; a.resid2 = resid2;
+    if (training) for (int st = 0; st <= H; ++st) a.amax[st] = sv.bound + size_t(8 + st) * kBoundWidth;
     a.store_mode = 1;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_LN, a, s))) return rc;
   }
@@ -338,6 +351,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.wh0 = reinterpret_cast<const float4*>(sv.n_w0xt);
     a.wh1 = reinterpret_cast<const float4*>(sv.n_w0at);
     a.dx = grad_x; a.dx2 = wk.daggr; a.dres = grad_out;
+    for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(24 + k) * kBoundWidth;
     if ((rc = launch_chain_bwd((int)D, G_ROWS_LN, F_HEADS2, a, s))) return rc;
   }
   // edge MLP backward (gradient of the aggregation = gather by target)
@@ -353,6 +367,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       a.mask[k] = sv.e_act[H - k - 1];
       a.gstore[k + 1] = wk.gE[H - k - 1];
     }
+    if (!bf) for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(16 + k) * kBoundWidth;
     if ((rc = launch_chain_bwd((int)D, G_EDGE_LN, F_NONE, a, s))) return rc;
   }
   // From here two independent strands run CONCURRENTLY (fork/join on an internal side stream):
@@ -374,17 +389,20 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   {
     WgradJob jobs[kMaxWgradJobs] = {};
     int nj = 0;
-    auto add_job = [&](const float* G, const float* A, float* dW, float* db, int64_t R, int ldw, int col0) {
+    // every operand comes with a magnitude bound from the chain kernel that produced or consumed it (GmpSaved::bound)
+    auto add_job = [&](const float* G, const float* A, float* dW, float* db, int64_t R, int ldw, int col0, const float* gb, const float* ab) {
       WgradJob& j = jobs[nj++];
       j.G = G; j.A = A; j.dW = dW; j.db = db; j.R = R; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldw; j.col0 = col0; j.bf16 = 0;
+      j.g_bound = gb; j.a_bound = ab; j.g_mul = j.a_mul = 1.f;
     };
+    auto bd = [&](int slot) { return sv.bound + size_t(slot) * kBoundWidth; };
     for (int l = 1; l <= H; ++l) {   // edge Linears: bf16 gradient and activation tensors in the bf16 precision
-      add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0);
+      add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0, bd(16 + (H - l)), bd(l - 1));
       jobs[nj - 1].bf16 = bf;
     }
-    for (int l = 1; l <= H; ++l) add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0);
-    add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0);
-    add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D);
+    for (int l = 1; l <= H; ++l) add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0, bd(24 + (H - l)), bd(8 + l));
+    add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0, bd(24 + H), bd(8));
+    add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D, bd(24 + H), bd(8));
     if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, ws))) return rc;
   }
   // a second side stream takes the remaining weight gradients of the first edge Linear (fiber columns + bias now,
@@ -429,9 +447,13 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     WgradJob jobs[2] = {};
     auto set = [&](WgradJob& j, const float* G, int col0) {
       j.G = G; j.A = x; j.dW = ge[0]; j.db = nullptr; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldE0; j.col0 = col0; j.bf16 = 0;
+      // dPs / dPd are sums of at most max-degree rows of gE[0]; x is covered by the joint bound of the node chain's input
+      if (!bf) { j.g_bound = sv.bound + size_t(16 + H) * kBoundWidth; j.a_bound = sv.bound + size_t(8) * kBoundWidth; j.a_mul = 1.f; }
     };
     set(jobs[0], wk.dPs, int(p + 1));
     set(jobs[1], wk.dPd, int(p + 1 + D));
+    jobs[0].g_mul = float(std::max<int64_t>(plan->max_out_degree, 1));   // scatter by source
+    jobs[1].g_mul = float(std::max<int64_t>(plan->max_in_degree, 1));    // scatter by target
     if ((rc = launch_wgrad((int)D, jobs, 2, wk.wg2, s2))) return rc;
   }
   // grad_x += dPs Wi + dPd Wj
@@ -466,6 +488,7 @@ MlpKind mlp_kind(int64_t in_dim, int64_t D, int64_t out_dim, int layer_norm) {
 struct MlpSaved {
   float *act[kMaxStages], *yln, *rstd;
   float *w[kMaxStages + 1], *wt[kMaxStages + 1], *w0t;
+  float* bound;   // training: magnitude bounds, [st] tensor entering forward MFMA stage st, [16 + k] gradient entering backward stage k
   size_t bytes;
 };
 MlpSaved carve_mlp_saved(void* base, int64_t R, int64_t D, int H, bool training = true) {
@@ -475,6 +498,7 @@ MlpSaved carve_mlp_saved(void* base, int64_t R, int64_t D, int H, bool training 
     for (int l = 0; l < H; ++l) s.act[l] = c.take(act_floats(size_t(R), D));
     s.yln = c.take(size_t(R) * D);
     s.rstd = c.take(size_t(R));
+    s.bound = c.take(size_t(kBoundSlots) * kBoundWidth);
   }
   for (int l = 0; l <= H; ++l) { s.w[l] = c.take(pack_floats(D)); if (training) s.wt[l] = c.take(pack_floats(D)); }
   s.w0t = c.take(size_t(16) * D);
@@ -538,6 +562,7 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
     add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.w[l], params[2 * l + 1]);
     if (training) add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.wt[l]);
   }
+  t.zero = training ? sv.bound : nullptr;
   if ((rc = launch_prepack(t, s))) return rc;
 
   ChainFwdArgs a{};
@@ -552,6 +577,7 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
   }
   a.nstage = st;
   a.y = y;
+  if (training) for (int k = 0; k < st; ++k) a.amax[k] = sv.bound + size_t(k) * kBoundWidth;
   if (kind == MLP_ROWS_SMALL) {
     a.wout = params[2 * H]; a.bout = params[2 * H + 1]; a.C = (int)out_dim;
     return launch_chain_fwd((int)D, IN_ROWS, OUT_SMALL, a, s);
@@ -601,6 +627,7 @@ extern "C" int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, i
     a.gstore[k + 1] = wk.g[l - 1];
   }
   a.nstage = k;
+  for (int q = 0; q <= k; ++q) a.gmax[q] = sv.bound + size_t(16 + q) * kBoundWidth;
   if (kind == MLP_SMALL_LN) {
     rc = launch_chain_bwd((int)D, G_ROWS_LN, F_NONE, a, s);
   } else {
@@ -624,6 +651,9 @@ extern "C" int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, i
     j.G = wk.g[l]; j.A = (l == 0) ? x : sv.act[l - 1];
     j.dW = grads[2 * l]; j.db = grads[2 * l + 1];
     j.R = R; j.ldg = j.lda = j.ldw = (int)D; j.col0 = 0;
+    j.g_bound = sv.bound + size_t(16 + (top - l)) * kBoundWidth;                          // g[l] = gstore[top - l]
+    j.a_bound = sv.bound + size_t(l - (kind == MLP_SMALL_LN ? 1 : 0)) * kBoundWidth;    // the tensor entering the forward stage of Linear l
+    j.g_mul = j.a_mul = 1.f;
   }
   if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, s))) return rc;
 

@@ -107,8 +107,12 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
     rowptr[gj[e] + 1]++;
     t_rowptr[gi[e] + 1]++;
   }
-  int64_t min_deg = E > 0 || N > 0 ? INT64_MAX : 0, max_src = -1;
-  for (int64_t n = 0; n < N; ++n) min_deg = std::min<int64_t>(min_deg, t_rowptr[n + 1]);
+  int64_t min_deg = E > 0 || N > 0 ? INT64_MAX : 0, max_src = -1, max_in = 0, max_out = 0;
+  for (int64_t n = 0; n < N; ++n) {
+    min_deg = std::min<int64_t>(min_deg, t_rowptr[n + 1]);
+    max_out = std::max<int64_t>(max_out, t_rowptr[n + 1]);
+    max_in = std::max<int64_t>(max_in, rowptr[n + 1]);
+  }
   if (N == 0) min_deg = 0;
   for (int64_t e = 0; e < E; ++e) max_src = std::max(max_src, gi[e]);
   std::partial_sum(rowptr.begin(), rowptr.end(), rowptr.begin());
@@ -142,6 +146,8 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
   p->E = E;
   p->min_out_degree = min_deg;
   p->max_source = max_src;
+  p->max_in_degree = max_in;
+  p->max_out_degree = max_out;
   int rc = BSMS_OK;
   if ((rc = upload(&p->rowptr, rowptr)) || (rc = upload(&p->src, src)) || (rc = upload(&p->dst, dst)) ||
       (rc = upload(&p->perm, perm)) || (rc = upload(&p->t_rowptr, t_rowptr)) ||

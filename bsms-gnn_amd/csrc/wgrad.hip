@@ -1,8 +1,11 @@
 // Weight-gradient kernels: dW = G^T A with the reduction over (up to millions of) edge / node rows.
 //
-// k_wgrad: split-K GEMM on v_mfma_f32_16x16x32_bf16 with the same exact three-way bf16 split as the chain kernels
-// (chain.h): both operands are fp32 in HBM, split ONCE per element while they are staged into LDS, and every
-// product is accumulated in fp32 as six bf16 partial products.  A workgroup owns one 128x128 block of dW and a
+// k_wgrad: split-K GEMM on the 16x16x32 matrix instructions with fp32 operands in HBM, split ONCE per element while they
+// are staged into LDS.  Two arithmetics (WgradJob::g_bound / a_bound, chain.h):
+//   H2   both operands come with a magnitude bound: fp16 x 2 pieces with one power-of-two scale per TENSOR (the
+//        reduction index is the row, so the chain kernels' per-row scales cannot be used) and three partial products
+//        h l + l h + h h per fragment pair -- the arithmetic of the chain kernels (chain.h);
+//   BF3  no bounds: the exact three-way bf16 split of rounds 1-2, six partial products (needs no range information).  A workgroup owns one 128x128 block of dW and a
 // contiguous slab of rows, 32 rows per chunk:
 //   stage   1024 threads load the chunk of G and of A row-major (16-byte loads, full 512-byte row bursts, three
 //           chunks ahead in registers), split every value into its hi/mid/lo bf16 and store three row-major bf16 planes per
@@ -17,6 +20,7 @@
 // small coarse levels still fill the chip.  The bias gradient (column sums of G) is accumulated in fp32 by the
 // staging threads.
 #include "chain.h"
+#include <cstdlib>
 #include <type_traits>
 
 using namespace bsms;
@@ -28,6 +32,7 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
 using s16x8 = __attribute__((ext_vector_type(8))) short;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int TB = 128;    // dW block edge
 constexpr int RC = 32;     // rows per chunk (= K of one MFMA)
 constexpr int LROW = 144;  // bf16 per LDS row: 128 columns + 16 pad (288 B: 8 banks further per row)
@@ -66,6 +71,26 @@ __device__ __forceinline__ void split_quad(const f32x4& v, u32x2& h, u32x2& m, u
   l[1] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
 }
 
+// fp16 pieces of s * x, two elements per dword (chain.hip: split_h2)
+__device__ __forceinline__ void split_h2(float x0, float x1, float s, unsigned& h, unsigned& l) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+}
+__device__ __forceinline__ void split_quad_h2(const f32x4& v, float s, u32x2& h, u32x2& l) {
+  unsigned h0, l0, h1, l1;
+  split_h2(v[0], v[1], s, h0, l0);
+  split_h2(v[2], v[3], s, h1, l1);
+  h = u32x2{h0, h1};
+  l = u32x2{l0, l1};
+}
+// biased exponent E of a bound (clamped so that 2^(139 - E) is a normal float); bound * 2^(139 - E) lies in [2^12, 2^13)
+__device__ __forceinline__ int bound_exp(float b) {
+  int E = int(__float_as_uint(b) >> 23) & 0xff;
+  return E < 12 ? 12 : E;
+}
+
 // MFMA operand of one 16-column block from a row-major plane: lane (c = lane & 15, q = lane >> 4) receives column
 // `col0 + c`, rows 4q..4q+3 (slots 0-3) and 16+4q..16+4q+3 (slots 4-7).  ds_read_b64_tr_b16: within a 16-lane group
 // lane i' supplies the 8 bytes at its address and lane i receives element (i & 3) of suppliers 4k + (i >> 2), k = 0..3
@@ -83,6 +108,9 @@ __device__ __forceinline__ bf16x8 column_fragment(const short* plane, int col0, 
 __device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mma_h(const bf16x8& a, const bf16x8& b, f32x4 c) {   // the same 16-bit lanes read as fp16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -91,9 +119,9 @@ constexpr int NPF = 3;            // chunks in flight in registers beyond the on
 static_assert(NPF == 3, "the step schedule in k_wgrad is written out for three register sets");
 
 // TIMING: experiments (profiles/wgrad_timeline.py); the production instantiation carries no stamps
-// JB: every job of the launch is a bf16 job (WgradJob::bf16); a compile-time switch so that the fp32 instantiation
-// keeps its branch-free load schedule
-template <bool TIMING, bool JB = false>
+// JB: every job of the launch is a bf16 job (WgradJob::bf16); H2: every job carries operand bounds (fp16 x 2 pieces);
+// compile-time switches so that every instantiation keeps its branch-free load schedule
+template <bool TIMING, bool JB = false, bool H2 = false>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   extern __shared__ __attribute__((aligned(16))) short planes[];  // [2 buffers][G|A][hi|mid|lo][32 rows][LROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,6 +135,29 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   const int64_t r1 = min(job.R, r0 + tab.rows_per_wg[j]);
   const int nchunk = int((r1 - r0 + RC - 1) / RC);
   const int n0 = bi * TB, k0 = bj * TB;
+  // H2: one power-of-two scale per operand tensor from its magnitude bound
+  int Eg = 139, Ea = 139;
+  float sG = 1.f, sA = 1.f;
+  if (H2) {   // bound = largest entry of the operand's bound slot (chain.h: kBoundWidth = 4 entries per thread)
+    static_assert(kBoundWidth == 4 * WG_THREADS, "one float4 of each bound slot per thread");
+    __shared__ unsigned bred[2][WG_THREADS / 64];
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const u32x4 gv = reinterpret_cast<const u32x4*>(job.g_bound)[tid], av = reinterpret_cast<const u32x4*>(job.a_bound)[tid];
+    unsigned gm = max(max(gv[0], gv[1]), max(gv[2], gv[3])), am = max(max(av[0], av[1]), max(av[2], av[3]));   // non-negative floats order like integers
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      gm = max(gm, (unsigned)__shfl_xor((int)gm, o, 64));
+      am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+    }
+    if (lane == 0) { bred[0][wave] = gm; bred[1][wave] = am; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WG_THREADS / 64; ++w) { gm = max(gm, bred[0][w]); am = max(am, bred[1][w]); }
+    Eg = bound_exp(__uint_as_float(gm) * job.g_mul);
+    Ea = bound_exp(__uint_as_float(am) * job.a_mul);
+    sG = __uint_as_float(unsigned(266 - Eg) << 23);
+    sA = __uint_as_float(unsigned(266 - Ea) << 23);
+  }
 
   // staging: 1024 threads move one 32-row chunk of G and of A, one float4 of each per thread (row = tid / 32,
   // columns 4 (tid % 32) ..): full 512-byte row bursts, NPF chunks ahead in registers
@@ -150,6 +201,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
       *reinterpret_cast<u32x2*>(dst + 3 * PLANE) = u32x2{__float_as_uint(aq[0]), __float_as_uint(aq[1])};
       if (want_db)
         csum += f32x4{__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u), __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
+      return;
+    }
+    if (H2) {   // planes 0 / 1: G pieces h / l; planes 3 / 4: A pieces h / l
+      split_quad_h2(gq, sG, h, l);
+      *reinterpret_cast<u32x2*>(dst + 0 * PLANE) = h;
+      *reinterpret_cast<u32x2*>(dst + 1 * PLANE) = l;
+      if (want_db) csum += gq;
+      split_quad_h2(aq, sA, h, l);
+      *reinterpret_cast<u32x2*>(dst + 3 * PLANE) = h;
+      *reinterpret_cast<u32x2*>(dst + 4 * PLANE) = l;
       return;
     }
     split_quad(gq, h, m, l);
@@ -205,6 +266,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
         const bf16x8 a1 = column_fragment(buf + 3 * PLANE, 32 * wc + 16 * b, lane);
         acc[0][b] = mma(g1[0], a1, acc[0][b]);
         acc[1][b] = mma(g1[1], a1, acc[1][b]);
+      }
+      return;
+    }
+    if (H2) {
+      bf16x8 g_h[2], g_l[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        g_h[a] = column_fragment(buf + 0 * PLANE, 32 * wr + 16 * a, lane);
+        g_l[a] = column_fragment(buf + 1 * PLANE, 32 * wr + 16 * a, lane);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bf16x8 a_h = column_fragment(buf + 3 * PLANE, 32 * wc + 16 * b, lane);
+        const bf16x8 a_l = column_fragment(buf + 4 * PLANE, 32 * wc + 16 * b, lane);
+        acc[0][b] = mma_h(g_h[0], a_l, acc[0][b]);
+        acc[1][b] = mma_h(g_h[1], a_l, acc[1][b]);
+        acc[0][b] = mma_h(g_l[0], a_h, acc[0][b]);
+        acc[1][b] = mma_h(g_l[1], a_h, acc[1][b]);
+        acc[0][b] = mma_h(g_h[0], a_h, acc[0][b]);
+        acc[1][b] = mma_h(g_h[1], a_h, acc[1][b]);
       }
       return;
     }
@@ -268,7 +349,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part[(32 * wr + 16 * a + 4 * q + r) * TB + 32 * wc + 16 * b + cc] = acc[a][b][r];
+      for (int r = 0; r < 4; ++r)   // H2: un-scale by the exact power of two 2^-(k_G + k_A) (ldexp: exact over the whole range)
+        part[(32 * wr + 16 * a + 4 * q + r) * TB + 32 * wc + 16 * b + cc] = H2 ? ldexpf(acc[a][b][r], Eg + Ea - 278) : acc[a][b][r];
   if (want_db) {  // combine the 32 row-threads of each column quad in fixed order through LDS
     f32x4* red = reinterpret_cast<f32x4*>(planes);
     red[tid] = csum;
@@ -501,7 +583,7 @@ size_t wgrad_work_bytes(int D, int njobs) {
   return size_t(kMaxTiles) * (TB * TB + TB) * sizeof(float);
 }
 
-static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t s, bool bf) {
+static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t s, bool bf, bool h2) {
   BSMS_REQUIRE(njobs >= 0 && njobs <= kMaxWgradJobs, BSMS_E_INVALID_ARG, "wgrad: %d jobs (max %d)", njobs, kMaxWgradJobs);
   BSMS_REQUIRE(D % 4 == 0 && D <= 256, BSMS_E_UNSUPPORTED, "wgrad: D=%d", D);
   if (njobs == 0) return BSMS_OK;
@@ -543,7 +625,12 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
   static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   BSMS_REQUIRE(attr == hipSuccess && attr_t == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS", lds);
-  if (bf) {
+  if (h2) {
+    static const hipError_t attr_h = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<false, false, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    BSMS_REQUIRE(attr_h == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (fp16 x 2 build)", lds);
+    hipLaunchKernelGGL((k_wgrad<false, false, true>), dim3(first), dim3(WG_THREADS), lds, s, tab);
+  } else if (bf) {
     static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<false, true>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     BSMS_REQUIRE(attr_b == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (bf16 build)", lds);
@@ -560,13 +647,19 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
 // second reusing the partial-block workspace after the first one's reduction
 int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t s) {
   BSMS_REQUIRE(njobs >= 0 && njobs <= kMaxWgradJobs, BSMS_E_INVALID_ARG, "wgrad: %d jobs (max %d)", njobs, kMaxWgradJobs);
+#ifdef BSMS_EXPERIMENTS
+  static const bool skip = getenv("BSMS_SKIP_WGRAD") != nullptr;   // timing experiments: what do the weight gradients cost the step?
+  if (skip) return BSMS_OK;
+#endif
   WgradJob part[kMaxWgradJobs];
-  for (int bf = 0; bf < 2; ++bf) {
+  for (int mode = 0; mode < 3; ++mode) {   // 0: fp32 with bounds (fp16 x 2), 1: fp32 without (bf16 x 3), 2: bf16 tensors
     int n = 0;
-    for (int j = 0; j < njobs; ++j)
-      if ((jobs[j].bf16 != 0) == (bf != 0)) part[n++] = jobs[j];
+    for (int j = 0; j < njobs; ++j) {
+      const int m = jobs[j].bf16 ? 2 : ((jobs[j].g_bound && jobs[j].a_bound) ? 0 : 1);
+      if (m == mode) part[n++] = jobs[j];
+    }
     if (n) {
-      int rc = launch_wgrad_same(D, part, n, work, s, bf != 0);
+      int rc = launch_wgrad_same(D, part, n, work, s, mode == 2, mode == 0);
       if (rc) return rc;
     }
   }
