@@ -79,30 +79,31 @@ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, uns
 __device__ __forceinline__ float pack_elem(const PackDesc& d, int n, int k) {
   return (d.kind == PACK_FRAG_T) ? d.W[int64_t(d.row0 + k) * d.ld + d.col0 + n] : d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
 }
-// pass 1 (one block per pack): 2^-k_w from the largest |M| of the matrix and of its mate -> header float kScaleSlot of
-// chunk 0, where pass 2 and the chain kernels read it
-__global__ __launch_bounds__(256) void k_pack_scale(PackTable tab) {
+// pass 1 (one 1024-thread block per pack): 2^-k_w from the largest |M| of the matrix and of its mate -> header float
+// kScaleSlot of chunk 0, where pass 2 and the chain kernels read it
+__global__ __launch_bounds__(1024) void k_pack_scale(PackTable tab) {
   if (tab.zero)   // clear the block's bound slots (chain.h: kBoundWidth), spread over the launch
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < kBoundSlots * kBoundWidth / 4; o += gridDim.x * 256)
+    for (int o = blockIdx.x * 1024 + threadIdx.x; o < kBoundSlots * kBoundWidth / 4; o += gridDim.x * 1024)
       reinterpret_cast<float4*>(tab.zero)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
   const PackDesc d = tab.d[blockIdx.x];
   if (d.kind == PACK_TRANSPOSE || d.bf16) return;
-  __shared__ float red[256];
+  __shared__ float red[16];
   float m = 0.f;
   auto scan = [&](const PackDesc& e) {   // coalesced along the rows of W whatever the logical orientation
     const int rows = (e.kind == PACK_FRAG_T) ? e.K : e.N, cols = (e.kind == PACK_FRAG_T) ? e.N : e.K;
-    for (int o = threadIdx.x; o < rows * cols; o += 256) m = fmaxf(m, fabsf(e.W[int64_t(e.row0 + o / cols) * e.ld + e.col0 + o % cols]));
+    const int tr = threadIdx.x / cols, tc = threadIdx.x % cols, step = 1024 / cols;   // cols divides 1024 (32 .. 256)
+    for (int r = tr; r < rows; r += step) m = fmaxf(m, fabsf(e.W[int64_t(e.row0 + r) * e.ld + e.col0 + tc]));
   };
   scan(d);
   if (d.mate) scan(tab.d[d.mate - 1]);
-  red[threadIdx.x] = m;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (int(threadIdx.x) < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
-    int Ew = int(__float_as_uint(red[0]) >> 23);
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    int Ew = int(__float_as_uint(m) >> 23);
     Ew = Ew < 13 ? 13 : (Ew > 254 ? 254 : Ew);            // 2^(139 - Ew) and its inverse are normal floats
     d.dst[kScaleSlot] = __uint_as_float(unsigned(Ew - 12) << 23);    // 2^(Ew - 139) = 2^-k_w
   }
@@ -1426,13 +1427,14 @@ inline int edge_rb_mode() {
 #endif
 }
 
-// Compute waves per workgroup of an edge launch.  At D = 256 a tile streams 1.2 MB of weight packs (8 chunks of 49 KB per
-// layer) and the LDS-DMA stream of a CU, not the matrix pipe, sets the pace: 7 compute waves (112-row tiles; one workgroup
-// per CU, 8 waves = two per SIMD at the 256-VGPR budget) spread that stream over 1.75x the rows.  At D = 128 stream
-// and compute are level and larger tiles measured +-0 (profiles/r02_edge_levels.md): 4.
+// Compute waves per workgroup of an edge launch: 7 (+ the loader: 8 waves, 112 x RB rows per tile).  A tile streams the
+// whole weight set of the MLP through the loader's LDS-DMA (one wave delivers a 1 KB piece per 60-185 cycles,
+// profiles/census/ldsdma_rate.hip), and since the fp32 products take three MFMAs per fragment pair that stream, not the
+// matrix pipe, paces a stage: 7 compute waves spread it over 1.75x the rows of 4 (same-box +2.5 % steps/s at D = 128 with
+// the fp16 x 2 arithmetic; +4.3 % at D = 256 already with the bf16 x 3 one; profiles/r02_edge_levels.md, r03).
 template <int NB>
 int edge_compute_waves() {
-  static const int cw = NB >= 16 ? knob("BSMS_EDGE_CW16", 7) : knob("BSMS_EDGE_CW", kComputeWaves);
+  static const int cw = NB >= 16 ? knob("BSMS_EDGE_CW16", 7) : knob("BSMS_EDGE_CW", 7);
   return cw;
 }
 template <int NB>
@@ -1471,8 +1473,8 @@ bool launch_edge_fwd(ChainFwdArgs& a, hipStream_t s, int& rc) {
   // block per wave win the forward (the random row gathers of one hide under the other's MFMA stages); a launch that
   // fits one round of workgroups is faster with two row blocks per wave, and so is the whole backward (its loads are
   // sequential or local).  Below half a round of 128-row tiles the narrow tile keeps more CUs busy.
-  const int64_t cus = device_cus();
-  bool big = RBIG == 2 && a.R >= cus * EdgeTile<NB, RBIG>::rows / 2 && ceil_div(a.R, EdgeTile<NB, 1>::rows) <= cus * EdgeTile<NB, 1>::resident;
+  const int64_t cus = device_cus(), rows1 = 16 * edge_compute_waves<NB>();   // rows of a tile with one row block per wave
+  bool big = RBIG == 2 && a.R >= cus * rows1 && ceil_div(a.R, rows1) <= cus * EdgeTile<NB, 1>::resident;
   if (edge_rb_mode() > 0) big = RBIG == 2 && edge_rb_mode() == 2;
   if (big) rc = save ? launch_edge_fwd_t<NB, RBIG, true>(a, s) : launch_edge_fwd_t<NB, RBIG, false>(a, s);
   else rc = save ? launch_edge_fwd_t<NB, 1, true>(a, s) : launch_edge_fwd_t<NB, 1, false>(a, s);
@@ -1499,7 +1501,7 @@ bool launch_edge_bwd(ChainBwdArgs& a, hipStream_t s, int& rc) {
   for (int k = 0; k <= a.nstage; ++k)
     if (!a.gstore[k] || (k < a.nstage && !a.mask[k])) return false;
   constexpr int RBIG = NB == 8 ? 2 : 1;
-  bool big = RBIG == 2 && a.R >= int64_t(device_cus()) * EdgeTile<NB, RBIG>::rows / 2;   // see launch_edge_fwd
+  bool big = RBIG == 2 && a.R >= int64_t(device_cus()) * 16 * edge_compute_waves<NB>();   // see launch_edge_fwd
   if (edge_rb_mode() > 0) big = RBIG == 2 && edge_rb_mode() == 2;
   rc = big ? launch_edge_bwd_t<NB, RBIG>(a, s) : launch_edge_bwd_t<NB, 1>(a, s);
   return true;
@@ -1633,7 +1635,7 @@ int launch_prepack(const PackTable& t, hipStream_t s) {
   int biggest = 0;
   for (int i = 0; i < t.n; ++i) biggest = biggest > t.d[i].N * t.d[i].K ? biggest : t.d[i].N * t.d[i].K;
   const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(biggest, 256), 64);
-  hipLaunchKernelGGL(k_pack_scale, dim3(t.n), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(k_pack_scale, dim3(t.n), dim3(1024), 0, s, t);
   BSMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_prepack, dim3(gx, t.n), dim3(256), 0, s, t);
   BSMS_LAUNCH_CHECK();
