@@ -39,7 +39,7 @@ WORKLOADS = {  # SURVEY.md section 8(d); BASELINE.json configs[1], [2]/[3], [4]
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate
 MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 flop/cycle x 2.4 GHz
-MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 6  # fp32 by exact 3-way bf16 split = six bf16 products per fp32 MAC
+MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 3  # fp32 by two-way fp16 split = three f16 products per fp32 MAC (f16 and bf16 MFMA peaks are equal)
 
 
 def mesh_points(kind, seed=None):
@@ -293,7 +293,7 @@ def roofline_objects(wl, batch, dtype="f32"):
     mf = {"kernel": "GMP forward at L0 (prepack + proj + k_chain_fwd edge/node + aggregation)", "bound": "mfma",
           "achieved": flops / (msf * 1e-3) / 1e12, "peak": MFMA_SPLIT_PEAK_TF, "unit": "TFLOP/s (fp32 flops)",
           "frac": flops / (msf * 1e-3) / 1e12 / MFMA_SPLIT_PEAK_TF, "flops": flops, "avg_us": msf * 1e3,
-          "peak_note": "dense bf16 MFMA peak / 6 (six bf16 partial products per fp32 multiply-add); "
+          "peak_note": "dense f16 MFMA peak / 3 (three fp16 partial products per fp32 multiply-add); "
                        f"for reference the f32-input MFMA peak is {MFMA_F32_PEAK_TF} TFLOP/s"}
     return roof, mf
 
@@ -414,7 +414,7 @@ def main():
             "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "arithmetic": ("fp32 in/out/accumulate; matrix products as exact 3-way bf16 splits on v_mfma_f32_16x16x32_bf16 (error <= f32 MFMA)"
+            "arithmetic": ("fp32 in/out/accumulate; matrix products as three partial products of two-way fp16 splits of power-of-two-scaled fp32 operands on v_mfma_f32_16x16x32_f16 (error <= f32 MFMA and <= fp32 FMA chain, profiles/census/f16split.hip)"
                            if args.dtype == "f32" else
                            "BSMS_BF16: edge activations / messages / edge layer gradients stored as bf16, edge-MLP products bf16 x bf16 "
                            "with fp32 accumulation; node level, LayerNorm, aggregation sums, encoder / decoder, loss, weight-gradient "

@@ -599,7 +599,12 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
   // 256 -> 130.5, 512 -> 128.0, 768 -> 126.5: long slabs amortise the pipeline fill and the partial-block traffic, a
   // grid that spills into a second, nearly empty round loses, and half the chip is left to the kernels that run
   // concurrently on the caller's stream.  Slabs are multiples of 6 chunks, at least 128 rows.
-  int64_t rows_per = std::max<int64_t>(128, ceil_div(total_rows * blocks, 128));
+#ifdef BSMS_EXPERIMENTS
+  static const int target_wgs = [] { const char* e = getenv("BSMS_WGRAD_WGS"); return e ? atoi(e) : 128; }();
+#else
+  constexpr int target_wgs = 128;
+#endif
+  int64_t rows_per = std::max<int64_t>(128, ceil_div(total_rows * blocks, target_wgs));
   rows_per = ceil_div(rows_per, 6 * RC) * (6 * RC);   // whole groups of six chunks (k_wgrad's step schedule)
   for (;;) {
     int64_t tiles = 0;

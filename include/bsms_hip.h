@@ -18,9 +18,11 @@
  *     per device, two lazily created internal side streams (+ two events each) that bsms_gmp_bwd uses to
  *     overlap its weight-gradient kernels with its gradient scatters (forked from and joined back into
  *     `stream` inside the call, also legal under HIP-graph capture).
- *   - Arithmetic: fp32 in, fp32 out, fp32 accumulation.  Matrix products run on the bf16 matrix cores as the
- *     six significant partial products of EXACT three-way bf16 splits of both fp32 operands; the result is
- *     at least as accurate as an fp32 fused-multiply-add chain (chain.h; tests/test_hip_parity.py).
+ *   - Arithmetic: fp32 in, fp32 out, fp32 accumulation.  Matrix products run on the f16 matrix cores as three
+ *     partial products of two-way fp16 splits (11 + 11 significand bits) of power-of-two-scaled fp32 operands --
+ *     scale per activation row and per weight matrix, per tensor in the weight gradients; the result is at least
+ *     as accurate as an fp32 fused-multiply-add chain and as v_mfma_f32_16x16x4_f32 over the whole fp32 range
+ *     (chain.h; profiles/census/f16split.hip; tests/test_hip_parity.py).
  *   - Edge lists follow the reference: g = int64 [2,E], g[0] = source i, g[1] = target j
  *     (ops/basic.py:66); aggregation target is j.  "Edge order" below = the caller's order of g.
  *   - `D` (latent width) must be a multiple of 32 for the MLP/GMP entries (MFMA tile width).

@@ -274,28 +274,45 @@ def test_gmp_other_widths(eng, D, p, H):
         assert rel_err(pm.grad.cpu(), pr.grad) < BWD_TOL, k
 
 
-def test_split_bf16_products_are_fp32_accurate(eng):
-    """The matrix cores multiply exact 3-way bf16 splits of the fp32 operands (chain.h).  Against an fp64 product
-    the engine's Linear must be at least as accurate as a plain fp32 matmul of the same data (not merely within
-    the 1e-5 parity tolerance): forward of one bias-free-equivalent layer stack and its weight gradient."""
+def test_split_products_are_fp32_accurate(eng):
+    """The matrix cores multiply fp16 x 2 pieces of power-of-two-scaled fp32 operands, three partial products (chain.h;
+    profiles/census/f16split.hip).  Against an fp64 computation the engine must be at least as accurate as plain fp32
+    arithmetic on the same data (not merely within the 1e-5 parity tolerance): forward of a Linear-ReLU-Linear-LayerNorm
+    stack, its input gradient and its weight gradients (the split-K kernel scales per tensor, wgrad.hip) -- also for
+    inputs and upstream gradients whose magnitudes vary by orders of magnitude between rows."""
     torch.manual_seed(11)
     R, D = 4096, 128
     ref = ro.MLP(D, D, D, 1, True)
-    mine = load_sd(eng.MLP(D, D, D, 1, True), ref.state_dict())
-    x = torch.randn(R, D)
-    w0, b0 = ref.state_dict()["seq.0.weight"], ref.state_dict()["seq.0.bias"]
-    w1, b1 = ref.state_dict()["seq.2.weight"], ref.state_dict()["seq.2.bias"]
-    def stack(xx, dt):
-        h = torch.relu(xx.to(dt) @ w0.to(dt).T + b0.to(dt))
-        z = h @ w1.to(dt).T + b1.to(dt)
-        return torch.nn.functional.layer_norm(z, (D,))
-    y64 = stack(x, torch.float64)
-    y32 = stack(x, torch.float32)
-    yd = mine(dev(x)).cpu()
-    err_engine = float((yd.double() - y64).abs().max())
-    err_fp32 = float((y32.double() - y64).abs().max())
-    assert err_engine <= 2.0 * err_fp32 + 1e-7, (err_engine, err_fp32)
-    assert rel_err(yd, y64.float()) < 1e-6
+    sd = ref.state_dict()
+    for scale_rows in (False, True):
+        x = torch.randn(R, D)
+        r = torch.randn(R, D)
+        if scale_rows:   # rows spanning 1e-4 .. 1e3 in the input, 1e-8 .. 1 in the upstream gradient
+            x = x * torch.logspace(-4, 3, R).unsqueeze(1)
+            r = r * torch.logspace(-8, 0, R)[torch.randperm(R)].unsqueeze(1)
+        def run(dt):
+            ws = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd.items()}
+            xx = x.to(dt).clone().requires_grad_(True)
+            h = torch.relu(xx @ ws["seq.0.weight"].T + ws["seq.0.bias"])
+            z = h @ ws["seq.2.weight"].T + ws["seq.2.bias"]
+            y = torch.nn.functional.layer_norm(z, (D,))
+            (y * r.to(dt)).sum().backward()
+            return y.detach(), xx.grad, {k: v.grad for k, v in ws.items()}
+        y64, gx64, gw64 = run(torch.float64)
+        y32, gx32, gw32 = run(torch.float32)
+        mine = load_sd(eng.MLP(D, D, D, 1, True), sd)
+        xd = dev(x).requires_grad_(True)
+        yd = mine(xd)
+        (yd * dev(r)).sum().backward()
+        got_w = dict(mine.named_parameters())
+        def err(a, b):   # error relative to the tensor scale
+            return float((a.double().cpu() - b).abs().max() / b.abs().max())
+        assert err(yd.detach(), y64) <= 2.0 * err(y32, y64) + 1e-7
+        assert err(xd.grad, gx64) <= 2.0 * err(gx32, gx64) + 1e-7, (scale_rows, err(xd.grad, gx64), err(gx32, gx64))
+        for k in gw64:
+            e_mine, e_32 = err(got_w[k].grad, gw64[k]), err(gw32[k], gw64[k])
+            assert e_mine <= 2.0 * e_32 + 1e-7, (scale_rows, k, e_mine, e_32)
+        assert rel_err(yd.detach().cpu(), y64.float()) < 1e-6
 
 
 # ------------------------------------------------------------------------------------ A8,A9 BSGMP
