@@ -108,6 +108,7 @@ struct ChainFwdArgs {
   int nseq;
   const float4* wseq[kMaxStages + 2];
   int nload;          // loader waves per workgroup (the last `nload` waves of the block)
+  int nring;          // depth of the LDS weight ring of this launch (3..6)
   // ---- magnitude bounds for the weight-gradient kernel (wgrad.hip): bound slots (kBoundWidth floats each, see above)
   // for the tensor ENTERING stage l -- amax[0]: x / [x, x2] / the activation of the narrow or edge input stage;
   // amax[l + 1]: the post-ReLU activation of stage l.  Nullable.
@@ -139,6 +140,7 @@ struct ChainBwdArgs {
   int nseq;
   const float4* wseq[kMaxStages + 2];
   int nload;          // loader waves per workgroup (the last `nload` waves of the block)
+  int nring;          // depth of the LDS weight ring of this launch (3..6)
   float* gmax[kMaxStages + 1];   // like ChainFwdArgs::amax for gstore[k] (the gradient entering stage k; [nstage]: the last one). Nullable.
 };
 

@@ -6,6 +6,9 @@ using namespace bsms;
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+#ifndef BSMS_CHAIN_WPE
+#define BSMS_CHAIN_WPE 4   // generic chain kernels, multi-round launches: 128-VGPR budget (two 8-wave workgroups per CU); single-round (LONE) variants take 256
+#endif
 constexpr int kPL = 2;   // fp16 planes per weight of the fp32 path (chain.h); the bf16 precision has one
 
 // Register layout ("chain layout", see chain.h): a wave owns 16 rows; lane l <-> row (l & 15), group g = l >> 4.
@@ -296,10 +299,15 @@ struct Ring {
   static constexpr int CHF = kChunkHdrFloats + NB * 256 * PL; // floats per chunk
   static constexpr int CH4 = CHF / 4;                         // float4 per chunk
   static constexpr int PER = CHF / 256;                       // LDS-DMA instructions (1 KB each) per chunk
-  static constexpr int NR = 3;                                // ring depth
-  static constexpr int SIDE_FLOATS = 8 * D;                   // side table after the ring: the edge MLP's fiber weights
-  static constexpr int BOUND_WORDS = 8 * 16;                  // after the side table: running magnitude bounds, 16 stages x 8 waves
-  static constexpr size_t lds_bytes = size_t(NR) * CHF * sizeof(float) + SIDE_FLOATS * sizeof(float) + BOUND_WORDS * sizeof(unsigned);
+  // LDS of a workgroup: [side table: the edge MLP's fiber weights][running magnitude bounds, 16 stages x 8 waves, padded
+  // to 1 KB][ring: nr chunks].  The ring depth nr is a LAUNCH parameter (3..6): nr - 1 chunks are in flight, and a lone
+  // workgroup per CU (coarse levels, node-level launches) is paced by the LDS-DMA latency of a chunk (~1 us) divided by
+  // the chunks in flight, not by any throughput -- deep rings for launches that fit one round of workgroups, 3 slots
+  // (two workgroups per CU) for the rest.
+  static constexpr int SIDE_FLOATS = 8 * D;
+  static constexpr int PRE_FLOATS = SIDE_FLOATS + 256;
+  static constexpr int PRE4 = PRE_FLOATS / 4;
+  static constexpr size_t lds_bytes(int nr) { return (size_t(PRE_FLOATS) + size_t(nr) * CHF) * sizeof(float); }
   static_assert(CHF % 256 == 0 && PER < 64, "chunk = whole LDS-DMA instructions, countable by vmcnt");
   static_assert(NB % 2 == 0, "K blocks are pairs of 16-feature blocks");
 };
@@ -315,8 +323,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int NB, int PL = kPL>
-__device__ __forceinline__ float* ring_side(float4* lds) { return reinterpret_cast<float*>(lds + Ring<NB, PL>::NR * Ring<NB, PL>::CH4); }
+// position in the ring: slot of the next chunk and the ring depth of this launch
+struct Slot { int i, nr; };
 
 // `side` (nullable, 8*D floats in HBM): copied once into the side table; the compute waves wait for it at one extra
 // barrier before their first tile.
@@ -325,15 +333,16 @@ __device__ __forceinline__ float* ring_side(float4* lds) { return reinterpret_ca
 // profiles/census/ldsdma_rate.hip: 39 / 61 / 87 GB/s per CU with 1 / 2 / 4 loader waves), and since the fp32 products
 // take three MFMAs per fragment pair instead of six the weight stream, not the matrix pipe, paces a stage.
 template <int NB, int PL, int NL, int LI>
-__device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles,
+__device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles, int nr,
                                            const float* side = nullptr) {
   using R = Ring<NB, PL>;
   constexpr int MINE = (R::PER - LI + NL - 1) / NL;   // pieces of a chunk this wave issues
   __builtin_amdgcn_s_setprio(3);                   // the loader must never be the wave the others wait for
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+  const unsigned pre0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+  const unsigned lds0 = pre0 + unsigned(R::PRE_FLOATS * sizeof(float));   // the ring
   if (side) {
     if (LI == 0) {
-      const unsigned dst = lds0 + unsigned(R::NR) * unsigned(R::CHF * sizeof(float));
+      const unsigned dst = pre0;
 #pragma unroll
       for (int i = 0; i < R::SIDE_FLOATS / 256; ++i) glds16(reinterpret_cast<const float4*>(side) + i * 64 + lane, dst + i * 1024);
     }
@@ -348,26 +357,33 @@ __device__ __forceinline__ void loader_run(const float4* const* wseq, int nseq, 
 #pragma unroll
     for (int i = 0; i < MINE; ++i) glds16(src + (LI + i * NL) * 64, dst + (LI + i * NL) * 1024);
     if (++ic == R::NCH) { ic = 0; if (++is == nseq) is = 0; }
-    if (++islot == R::NR) islot = 0;
+    if (++islot == nr) islot = 0;
   };
-  if (total > 0) issue();
-  if (total > 1) issue();
+  const int ahead = nr - 1;                        // chunks in flight
+  for (int j = 0; j < ahead && j < total; ++j) issue();
   for (int j = 0; j < total; ++j) {
-    // chunk j has landed once at most the (whole) younger chunk is still outstanding
-    if (j + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINE) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // chunk j has landed once at most the younger chunks (issued after it: up to nr - 2) are still outstanding; the
+    // launcher guarantees (nr - 2) * MINE <= 63 (the vmcnt field)
+    const int younger = min(ahead - 1, total - 1 - j);
+    switch (younger) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINE) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MINE <= 63 ? 2 * MINE : 63) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * MINE <= 63 ? 3 * MINE : 63) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * MINE <= 63 ? 4 * MINE : 63) : "memory"); break;
+    }
     asm volatile("s_barrier" ::: "memory");       // barrier #j: publishes chunk j; everyone is done with chunk j-1,
-    if (j + 2 < total) issue();                    // whose slot chunk j+2 now overwrites
+    if (j + ahead < total) issue();                // whose slot chunk j + nr - 1 now overwrites
   }
 }
 // loader wave `li` of `nl` (1..3)
 template <int NB, int PL = kPL>
 __device__ __forceinline__ void loader_dispatch(int nl, int li, const float4* const* wseq, int nseq, float4* lds, int lane, int ntiles,
-                                                const float* side = nullptr) {
-  if (nl == 1) loader_run<NB, PL, 1, 0>(wseq, nseq, lds, lane, ntiles, side);
-  else if (nl == 2) { if (li == 0) loader_run<NB, PL, 2, 0>(wseq, nseq, lds, lane, ntiles, side); else loader_run<NB, PL, 2, 1>(wseq, nseq, lds, lane, ntiles, side); }
-  else { if (li == 0) loader_run<NB, PL, 3, 0>(wseq, nseq, lds, lane, ntiles, side); else if (li == 1) loader_run<NB, PL, 3, 1>(wseq, nseq, lds, lane, ntiles, side);
-         else loader_run<NB, PL, 3, 2>(wseq, nseq, lds, lane, ntiles, side); }
+                                                int nr, const float* side = nullptr) {
+  if (nl == 1) loader_run<NB, PL, 1, 0>(wseq, nseq, lds, lane, ntiles, nr, side);
+  else if (nl == 2) { if (li == 0) loader_run<NB, PL, 2, 0>(wseq, nseq, lds, lane, ntiles, nr, side); else loader_run<NB, PL, 2, 1>(wseq, nseq, lds, lane, ntiles, nr, side); }
+  else { if (li == 0) loader_run<NB, PL, 3, 0>(wseq, nseq, lds, lane, ntiles, nr, side); else if (li == 1) loader_run<NB, PL, 3, 1>(wseq, nseq, lds, lane, ntiles, nr, side);
+         else loader_run<NB, PL, 3, 2>(wseq, nseq, lds, lane, ntiles, nr, side); }
 }
 
 // 16-bit pieces of one lane's activations as B operands: plane[kb2] = 8 values = slots i of K block kb2 (chain.h)
@@ -419,9 +435,9 @@ __device__ __forceinline__ float row_amax(const f32x4 (&v)[NB]) {
 // it writes them to its entry of the bound slots.  `m` is a row maximum (>= 0, the same in the four lanes of a row): max
 // over the wave's 16 rows with DPP, then one lane updates the LDS word.  Bit patterns of non-negative floats order like
 // integers (inf / nan rows publish inf / nan: the consumer's results are then inf / nan too, as in the reference).
-template <int NB, int PL = kPL>
+template <int NB>
 __device__ __forceinline__ unsigned* bound_row(float4* lds, int wave, int lane) {
-  unsigned* row = reinterpret_cast<unsigned*>(ring_side<NB, PL>(lds) + Ring<NB, PL>::SIDE_FLOATS) + wave * 16;
+  unsigned* row = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(lds) + Ring<NB>::SIDE_FLOATS) + wave * 16;
   if (lane < 16) row[lane] = 0u;
   return row;
 }
@@ -473,7 +489,7 @@ __device__ __forceinline__ void finish_stage(f32x4 (&acc)[NB], int E, int fw, co
 // bf16 precision (chain.h): operands are the bf16 roundings of `act` and of the weights (one plane per pack, bias in the
 // header of chunk 0), ONE product per fragment pair; `store_base` receives bf16 rows.
 template <int NB>
-__device__ __forceinline__ void mfma_stage_bf(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, int& slot, int lane,
+__device__ __forceinline__ void mfma_stage_bf(f32x4 (&acc)[NB], const f32x4 (&act)[NB], float4* lds, Slot& slot, int lane,
                                               bool from_header, float* store_base, int64_t store_off, int64_t mask_rows) {
   using R = Ring<NB, 1>;
   u32x4 bb[NB / 2];
@@ -482,8 +498,8 @@ __device__ __forceinline__ void mfma_stage_bf(f32x4 (&acc)[NB], const f32x4 (&ac
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     lds_barrier();
-    const float4* cur = lds + slot * R::CH4;
-    if (++slot == R::NR) slot = 0;
+    const float4* cur = lds + slot.i * R::CH4;
+    if (++slot.i == slot.nr) slot.i = 0;
     if (c == 0 && from_header) {
       const float* bl_ = reinterpret_cast<const float*>(cur);
 #pragma unroll
@@ -517,8 +533,8 @@ __device__ __forceinline__ void mfma_stage_bf(f32x4 (&acc)[NB], const f32x4 (&ac
 // `slot` = ring slot of the stage's first chunk (advanced here).  `rs`: scale of this lane's row (scale_of(row_amax)).
 // `store_base` (nullable, uniform) + `row` / `nrows`: HBM tensor that receives `act` as streaming 128-byte pairs, one
 // pair per chunk, + its ReLU sign bits when `mask_rows`.  All compute waves of the workgroup must call this together.
-template <int NB, bool ZERO, int FIN, bool TIMED = false>
-__device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], const RowScale rs, float4* lds, int& slot,
+template <int NB, bool ZERO, int FIN, bool LONE = false, bool TIMED = false>
+__device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[NB], const RowScale rs, float4* lds, Slot& slot,
                                            int lane, float* store_base = nullptr, int64_t store_off = -1,
                                            int store_mode = 0, int64_t mask_rows = 0,
                                            unsigned long long* waited = nullptr, int64_t row = 0, int64_t nrows = 0) {
@@ -549,29 +565,61 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
     } else {
       lds_barrier();                                         // chunk has landed (and my reads of the last one are done)
     }
-    const float4* cur = lds + slot * R::CH4;
-    if (++slot == R::NR) slot = 0;
+    const float4* cur = lds + slot.i * R::CH4;
+    if (++slot.i == slot.nr) slot.i = 0;
     if (c == 0) fw = int(__float_as_uint(reinterpret_cast<const float*>(cur)[kScaleSlot]) >> 23);
     if (paired) store_pair_stream<NB>(act, store_base, row, nrows, lane, 2 * c, streaming);
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
-    // two accumulators interleaved so that back-to-back MFMAs are independent; one weight plane at a time
+    // Two accumulators interleaved so that back-to-back MFMAs are independent.
+    if constexpr (LONE) {
+      // A launch of one round of workgroups has a single wave per SIMD; with a fragment read right in front of its MFMAs
+      // that wave sat out an LDS round trip per pair (~350 cycles per six MFMAs: the "24 us floor" of every node-level
+      // launch at the coarse levels).  Here pairs are read ONE PAIR AHEAD (f = current, n = next), pinned by
+      // sched_barrier.  (With two or three waves per SIMD the compiler's own order is faster: the other variant.)
+      float4 f0 = body[0], f1 = body[2 * 64];                                      // (t = 0, plane h)
 #pragma unroll
-    for (int t = 0; t < NB; t += 2) {
-      {
-        const float4 h0 = body[(t * 2 + 0) * 64], h1 = body[(t * 2 + 2) * 64];
-        acc[t] = mma(h0, bl[c], (ZERO && c == 0) ? zero : acc[t]);
-        acc[t + 1] = mma(h1, bl[c], (ZERO && c == 0) ? zero : acc[t + 1]);
-        acc[t] = mma(h0, bh[c], acc[t]);
-        acc[t + 1] = mma(h1, bh[c], acc[t + 1]);
+      for (int t = 0; t < NB; t += 2) {
+        float4 n0 = body[(t * 2 + 1) * 64], n1 = body[(t * 2 + 3) * 64];          // plane l of (t, t + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t] = mma(f0, bl[c], (ZERO && c == 0) ? zero : acc[t]);
+        acc[t + 1] = mma(f1, bl[c], (ZERO && c == 0) ? zero : acc[t + 1]);
+        acc[t] = mma(f0, bh[c], acc[t]);
+        acc[t + 1] = mma(f1, bh[c], acc[t + 1]);
+        if (t == 0) {   // VALU work for later, placed among this chunk's MFMAs
+          if (c + 1 < R::NCH) split_block<NB>(act, c + 1, rs.s, bh[c + 1], bl[c + 1]);
+          else if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);
+        }
+        f0 = n0;
+        f1 = n1;
+        if (t + 2 < NB) {                                                           // plane h of the next block pair
+          n0 = body[((t + 2) * 2) * 64];
+          n1 = body[((t + 2) * 2 + 2) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t] = mma(f0, bh[c], acc[t]);
+        acc[t + 1] = mma(f1, bh[c], acc[t + 1]);
+        f0 = n0;
+        f1 = n1;
       }
-      if (t == 0) {   // VALU work for later, placed among this chunk's MFMAs
-        if (c + 1 < R::NCH) split_block<NB>(act, c + 1, rs.s, bh[c + 1], bl[c + 1]);
-        else if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);  // saved activation: + sign bits
-      }
-      {
-        const float4 l0 = body[(t * 2 + 1) * 64], l1 = body[(t * 2 + 3) * 64];
-        acc[t] = mma(l0, bh[c], acc[t]);
-        acc[t + 1] = mma(l1, bh[c], acc[t + 1]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NB; t += 2) {
+        {
+          const float4 h0 = body[(t * 2 + 0) * 64], h1 = body[(t * 2 + 2) * 64];
+          acc[t] = mma(h0, bl[c], (ZERO && c == 0) ? zero : acc[t]);
+          acc[t + 1] = mma(h1, bl[c], (ZERO && c == 0) ? zero : acc[t + 1]);
+          acc[t] = mma(h0, bh[c], acc[t]);
+          acc[t + 1] = mma(h1, bh[c], acc[t + 1]);
+        }
+        if (t == 0) {   // VALU work for later, placed among this chunk's MFMAs
+          if (c + 1 < R::NCH) split_block<NB>(act, c + 1, rs.s, bh[c + 1], bl[c + 1]);
+          else if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);  // saved activation: + sign bits
+        }
+        {
+          const float4 l0 = body[(t * 2 + 1) * 64], l1 = body[(t * 2 + 3) * 64];
+          acc[t] = mma(l0, bh[c], acc[t]);
+          acc[t + 1] = mma(l1, bh[c], acc[t + 1]);
+        }
       }
     }
     if (FIN != 0 && c == R::NCH - 1) finish_stage<NB, FIN == 2>(acc, rs.E, fw, reinterpret_cast<const float*>(cur), lane);
@@ -616,14 +664,14 @@ __device__ __forceinline__ float dot_features(const f32x4 (&v)[NB], const float*
 // -------------------------------------------------------------------------------- forward chain
 // TIMING (experiments, profiles/tile_timeline.py): phase stamps of wave 0; a separate instantiation so that the
 // production kernel carries none of it.
-template <int NB, int IN, int OUT, bool TIMING = false, bool BF = false>
-__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_fwd(ChainFwdArgs a) {
+template <int NB, int IN, int OUT, bool TIMING = false, bool BF = false, bool LONE = false>
+__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? (LONE ? 2 : BSMS_CHAIN_WPE) : 2))) void k_chain_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   const int cw = int(blockDim.x >> 6) - a.nload;   // compute waves of this launch (4..7, chosen by the launcher); the last wave(s) load
   if (wave >= cw) {  // loader wave (uniform branch)
-    loader_dispatch<NB, BF ? 1 : kPL>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles, IN == IN_EDGE ? a.w0t : nullptr);
+    loader_dispatch<NB, BF ? 1 : kPL>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles, a.nring, IN == IN_EDGE ? a.w0t : nullptr);
     return;
   }
   // IN_EDGE: the fiber weights are read from the LDS side table (read from HBM/L2 they cost one dependent round
@@ -631,10 +679,11 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   const float* w0t = a.w0t;
   if (IN == IN_EDGE) {
     lds_barrier();
-    w0t = ring_side<NB, BF ? 1 : kPL>(lds);
+    w0t = reinterpret_cast<const float*>(lds);
   }
-  int slot = 0;  // ring slot of the next chunk; runs on across this workgroup's tiles exactly like the loader's
-  unsigned* brow = bound_row<NB, BF ? 1 : kPL>(lds, wave, lane);   // this wave's running magnitude bounds
+  Slot slot{0, a.nring};  // ring slot of the next chunk; runs on across this workgroup's tiles exactly like the loader's
+  float4* const ring = lds + Ring<NB>::PRE4;
+  unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
   // Persistent workgroups: the grid is sized to what the chip holds at once and strides over the tiles, so a CU
   // never waits for the dispatcher to refill a slot (measured: 20-35 % of slot time was empty with one
   // workgroup per tile) and the loader is already fetching the next tile's first chunk during this epilogue.
@@ -718,15 +767,15 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     const float m = row_amax<NB>(act);
     note_amax(brow, 0, m, lane);
     const RowScale rs = scale_of(m);
-    mfma_stage<NB, true, 2>(acc, act, rs, lds, slot, lane);
+    mfma_stage<NB, true, 2, LONE>(acc, act, rs, ring, slot, lane);
     store_rows<NB, false>(acc, a.y, roff, lg);
-    mfma_stage<NB, true, 2>(acc, act, rs, lds, slot, lane);
+    mfma_stage<NB, true, 2, LONE>(acc, act, rs, ring, slot, lane);
     store_rows<NB, false>(acc, a.y2, roff, lg);
     continue;
   }
   for (int l = 0; l < a.nstage; ++l) {
     if constexpr (BF) {
-      mfma_stage_bf<NB>(acc, act, lds, slot, lane, true, pending, roff, (a.store_mode & 4) ? 0 : a.R);   // acc = bias + W act
+      mfma_stage_bf<NB>(acc, act, ring, slot, lane, true, pending, roff, (a.store_mode & 4) ? 0 : a.R);   // acc = bias + W act
     } else if (IN == IN_ROWS2 && l == 0) {
       // Linear over the concatenation [x, x2]: ONE row scale (the larger of the two rows' maxima; the second source is
       // read once more for it -- node-level rows, L2-resident) and one weight scale (PackDesc::mate), so the second half
@@ -736,13 +785,13 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
       m = fmaxf(m, row_amax<NB>(acc));
       note_amax(brow, 0, m, lane);
       const RowScale rs = scale_of(m);
-      mfma_stage<NB, true, 0>(acc, act, rs, lds, slot, lane);
+      mfma_stage<NB, true, 0, LONE>(acc, act, rs, ring, slot, lane);
       load_rows<NB>(act, a.x2 + rowc * D, lg);
-      mfma_stage<NB, false, 2>(acc, act, rs, lds, slot, lane);
+      mfma_stage<NB, false, 2, LONE>(acc, act, rs, ring, slot, lane);
     } else {
       const float m = row_amax<NB>(act);
       note_amax(brow, l, m, lane);
-      mfma_stage<NB, true, 2, TIMING>(acc, act, scale_of(m), lds, slot, lane, pending, roff, a.store_mode & 3,
+      mfma_stage<NB, true, 2, LONE, TIMING>(acc, act, scale_of(m), ring, slot, lane, pending, roff, a.store_mode & 3,
                                       (a.store_mode & 4) ? 0 : a.R, &waited, row, (a.store_mode & 8) ? 0 : a.R);  // acc = bias + W act
     }
     stamp();          // stage l done
@@ -826,18 +875,19 @@ __device__ __forceinline__ void mask_by(f32x4 (&gr)[NB], const float* act_row, i
   }
 }
 
-template <int NB, int GIN, int FIRST, bool BF = false>
-__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? 4 : 2))) void k_chain_bwd(ChainBwdArgs a) {
+template <int NB, int GIN, int FIRST, bool BF = false, bool LONE = false>
+__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(NB <= 8 ? (LONE ? 2 : BSMS_CHAIN_WPE) : 2))) void k_chain_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   const int cw = int(blockDim.x >> 6) - a.nload;   // compute waves of this launch (4..7, chosen by the launcher); the last wave(s) load
   if (wave >= cw) {  // loader wave (uniform branch)
-    loader_dispatch<NB, BF ? 1 : kPL>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles);
+    loader_dispatch<NB, BF ? 1 : kPL>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles, a.nring);
     return;
   }
-  int slot = 0;  // ring slot of the next chunk, across this workgroup's tiles
-  unsigned* brow = bound_row<NB, BF ? 1 : kPL>(lds, wave, lane);   // this wave's running magnitude bounds
+  Slot slot{0, a.nring};  // ring slot of the next chunk, across this workgroup's tiles
+  float4* const ring = lds + Ring<NB>::PRE4;
+  unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {  // persistent workgroups (see k_chain_fwd)
   const int64_t row = int64_t(tile) * (16 * cw) + wave * 16 + (lane & 15);
   const bool live = row < a.R;
@@ -889,11 +939,11 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
                            : 0xffffffffu;
     if constexpr (BF) {
       zero_tile<NB>(acc);
-      mfma_stage_bf<NB>(acc, g, lds, slot, lane, false, pending, roff, 0);
+      mfma_stage_bf<NB>(acc, g, ring, slot, lane, false, pending, roff, 0);
     } else {
       const float m = row_amax<NB>(g);
       note_amax(brow, k, m, lane);
-      mfma_stage<NB, true, 1>(acc, g, scale_of(m), lds, slot, lane, pending, roff, a.store_mode & 3, 0, nullptr, row,
+      mfma_stage<NB, true, 1, LONE>(acc, g, scale_of(m), ring, slot, lane, pending, roff, a.store_mode & 3, 0, nullptr, row,
                               (a.store_mode & 8) ? 0 : a.R);
     }
 #pragma unroll
@@ -910,7 +960,7 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     const float mh = row_amax<NB>(g);
     note_amax(brow, a.nstage, mh, lane);
     const RowScale rs = scale_of(mh);
-    mfma_stage<NB, true, 1>(acc, g, rs, lds, slot, lane, pending, roff, 1, 0, nullptr, row, a.R);
+    mfma_stage<NB, true, 1, LONE>(acc, g, rs, ring, slot, lane, pending, roff, 1, 0, nullptr, row, a.R);
     pending = nullptr;
     if (a.dres) {
       f32x4 r[NB];
@@ -920,7 +970,7 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     }
     if (FIRST == F_HEADS2) {
       f32x4 acc2[NB];
-      mfma_stage<NB, true, 1>(acc2, g, rs, lds, slot, lane);
+      mfma_stage<NB, true, 1, LONE>(acc2, g, rs, ring, slot, lane);
       store_rows<NB, false>(acc, a.dx, roff, lg);
       store_rows<NB, false>(acc2, a.dx2, roff, lg);
     } else {
@@ -1040,7 +1090,7 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
 
 // HDR: acc = bias + W act (forward); else acc = W act (backward).  The accumulators start from zero either way.
 template <int NB, int RB, bool SAVE, bool MASK, bool HDR>
-__device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, int& slot, int lane,
+__device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, Slot& slot, int lane,
                                          float* store_base, unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB],
                                          unsigned* brow, int stage) {
   using Rg = Ring<NB>;
@@ -1069,8 +1119,8 @@ __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act
 #pragma unroll
   for (int c = 0; c < Rg::NCH; ++c) {
     lds_barrier();                                         // chunk has landed (and my reads of the last one are done)
-    const float4* cur = lds + slot * Rg::CH4;
-    if (++slot == Rg::NR) slot = 0;
+    const float4* cur = lds + slot.i * Rg::CH4;
+    if (++slot.i == slot.nr) slot.i = 0;
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
     float4 f0 = body[0], f1 = body[2 * 64];                // pair (t = 0, plane h)
     if (c == 0) fw = int(__float_as_uint(reinterpret_cast<const float*>(cur)[kScaleSlot]) >> 23);
@@ -1138,7 +1188,7 @@ void k_edge_fwd(ChainFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   const int cw = int(blockDim.x >> 6) - a.nload, tile_rows = 16 * RB * cw;   // compute waves of this launch (launcher's choice); the last wave(s) load
   if (wave >= cw) {  // loader wave (uniform branch)
-    loader_dispatch<NB>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles, a.w0t);
+    loader_dispatch<NB>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles, a.nring, a.w0t);
     return;
   }
   const float rcpE = 1.f / float(a.E);
@@ -1157,8 +1207,9 @@ void k_edge_fwd(ChainFwdArgs a) {
   int ni[RB], nj[RB], nbat[RB];
   fetch_endpoints(blockIdx.x, ni, nj, nbat);
   lds_barrier();
-  const float* w0t = ring_side<NB>(lds);   // fiber weights (LDS side table, see k_chain_fwd)
-  int slot = 0;
+  const float* w0t = reinterpret_cast<const float*>(lds);   // fiber weights (LDS side table, see k_chain_fwd)
+  Slot slot{0, a.nring};
+  float4* const ring = lds + Ring<NB>::PRE4;
   unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int64_t row[RB];
@@ -1232,7 +1283,7 @@ void k_edge_fwd(ChainFwdArgs a) {
     for (int l = 0; l < a.nstage; ++l) {
       float* st_tile = SAVE ? pending + int64_t(tile) * (tile_rows * D) : nullptr;   // uniform
       unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (tile_rows * 4 * mask_words<NB>()) : nullptr;
-      stage_rb<NB, RB, SAVE, true, true>(acc, act, lds, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
+      stage_rb<NB, RB, SAVE, true, true>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
       stamp();
       if (l + 1 < a.nstage) {
 #pragma unroll
@@ -1276,7 +1327,7 @@ void k_edge_bwd(ChainBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4;
   const int cw = int(blockDim.x >> 6) - a.nload, tile_rows = 16 * RB * cw;   // compute waves of this launch (launcher's choice); the last wave(s) load
   if (wave >= cw) {  // loader wave (uniform branch)
-    loader_dispatch<NB>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles);
+    loader_dispatch<NB>(a.nload, wave - cw, a.wseq, a.nseq, lds, lane, a.ntiles, a.nring);
     return;
   }
   const float rcpE = 1.f / float(a.E);
@@ -1290,7 +1341,8 @@ void k_edge_bwd(ChainBwdArgs a) {
   };
   int64_t nnode[RB];
   fetch_targets(blockIdx.x, nnode);
-  int slot = 0;
+  Slot slot{0, a.nring};
+  float4* const ring = lds + Ring<NB>::PRE4;
   unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int64_t row[RB], rowc[RB];
@@ -1333,7 +1385,7 @@ void k_edge_bwd(ChainBwdArgs a) {
 #pragma unroll
         for (int w = 0; w < W; ++w)
           mbits[rb][w] = reinterpret_cast<const unsigned*>(a.mask[k] + pad_rows(a.R) * D)[rowc[rb] * (4 * W) + lg * W + w];
-      stage_rb<NB, RB, true, false, false>(acc, g, lds, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff, brow, k);
+      stage_rb<NB, RB, true, false, false>(acc, g, ring, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff, brow, k);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -1447,16 +1499,36 @@ inline int chain_loader_waves() {
   return nl;
 }
 
+// Weight stream of a launch: loader waves and ring depth (Ring).  A launch that fits ONE round of workgroups (at most
+// one workgroup per CU: the coarse mesh levels, most node-level launches) has the CU's whole LDS and nothing to overlap
+// its chunk latency with: deep ring (up to 6 slots = 5 chunks in flight) fed by two loader waves.  Anything larger keeps
+// 3 slots so that two workgroups share a CU.  Limits: compute + loader waves <= 8; (nr - 2) x pieces per loader <= 63
+// (vmcnt field); ring + side tables <= 160 KB.
+template <int NB, int PL = kPL>
+int max_ring() { return (int)std::min<size_t>(6, (size_t(160) * 1024 - Ring<NB, PL>::PRE_FLOATS * sizeof(float)) / (Ring<NB, PL>::CHF * sizeof(float))); }
+template <int NB, int PL = kPL>
+void pick_stream(int64_t ntiles, int cw, int nload_default, int& nload, int& nring) {
+  static const int deep = knob("BSMS_RING_DEEP", 6), lone_nl = knob("BSMS_LONE_NL", 2);
+  nload = std::max(1, std::min(nload_default, 8 - cw));
+  nring = 3;
+  if (ntiles <= device_cus()) {
+    nload = std::max(nload, std::min(lone_nl, 8 - cw));
+    nring = std::min(deep, max_ring<NB, PL>());
+  }
+  const int mine = (Ring<NB, PL>::PER + nload - 1) / nload;
+  while (nring > 3 && (nring - 2) * mine > 63) --nring;
+}
+
 template <int NB, int RB, bool SAVE>
 int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
-  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   const int cw = edge_compute_waves<NB>();
-  a.nload = edge_loader_waves<NB>();
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
+  pick_stream<NB>(a.ntiles, cw, edge_loader_waves<NB>(), a.nload, a.nring);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
-  hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes, s, a);
+  hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes(a.nring), s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -1484,13 +1556,13 @@ bool launch_edge_fwd(ChainFwdArgs& a, hipStream_t s, int& rc) {
 template <int NB, int RB>
 int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
-  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   const int cw = edge_compute_waves<NB>();
-  a.nload = edge_loader_waves<NB>();
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
+  pick_stream<NB>(a.ntiles, cw, edge_loader_waves<NB>(), a.nload, a.nring);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
-  hipLaunchKernelGGL((k_edge_bwd<NB, RB>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes, s, a);
+  hipLaunchKernelGGL((k_edge_bwd<NB, RB>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes(a.nring), s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }
@@ -1515,23 +1587,24 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
     a.wseq[a.nseq++] = a.wp[l];
     if (IN == IN_ROWS2 && l == 0) a.wseq[a.nseq++] = a.wp0b;
   }
-  const size_t lds = Ring<NB>::lds_bytes;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
-  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve %zu bytes of LDS", lds);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   if constexpr ((NB == 8 || NB == 16) && IN == IN_EDGE && OUT == OUT_LN) {
     int rc = BSMS_OK;
     if (launch_edge_fwd<NB>(a, s, rc)) return rc;
   }
   const int cw = (IN == IN_EDGE) ? kComputeWaves : chain_compute_waves<NB>(a.R);
-  a.nload = std::min(chain_loader_waves(), 8 - cw);
-  const dim3 threads((cw + a.nload) * 64);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
+  if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
+  else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
+  const dim3 threads((cw + a.nload) * 64);
+  const size_t lds = Ring<NB>::lds_bytes(a.nring);   // (the bf16 precision's chunks are smaller: the same allocation covers them)
   bool launched = false;
   if constexpr (NB == 8 && IN == IN_EDGE) {   // the only instantiation with stamps
     if (a.timing) {
       static const hipError_t tattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(tattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (timing build)");
       hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       launched = true;
@@ -1540,13 +1613,22 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   if constexpr ((NB == 8 || NB == 16) && IN == IN_EDGE && OUT == OUT_LN) {   // the bf16 precision exists for the edge MLP only
     if (a.bf16 && !launched) {
       static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(battr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (bf16 build)");
       hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       launched = true;
     }
   }
   BSMS_REQUIRE(launched || !a.bf16, BSMS_E_UNSUPPORTED, "chain_fwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
+  if constexpr (NB >= 8) {   // one round of workgroups = a single wave per SIMD: the variant that prefetches its fragments (mfma_stage)
+    if (!launched && a.ntiles <= device_cus()) {
+      static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, false, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (single-round build)");
+      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
+      launched = true;
+    }
+  }
   if (!launched)
     hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
   BSMS_LAUNCH_CHECK();
@@ -1576,21 +1658,22 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   for (int k = 0; k < a.nstage; ++k) a.wseq[a.nseq++] = a.wpt[k];
   if (FIRST != F_NONE) a.wseq[a.nseq++] = a.wh0;
   if (FIRST == F_HEADS2) a.wseq[a.nseq++] = a.wh1;
-  const size_t lds = Ring<NB>::lds_bytes;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
-  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", lds);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+  BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   const int cw = (GIN == G_EDGE_LN) ? kComputeWaves : chain_compute_waves<NB>(a.R);
-  a.nload = std::min(chain_loader_waves(), 8 - cw);
-  const dim3 threads((cw + a.nload) * 64);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
+  if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
+  else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
+  const dim3 threads((cw + a.nload) * 64);
+  const size_t lds = Ring<NB>::lds_bytes(a.nring);
   if constexpr ((NB == 8 || NB == 16) && GIN == G_EDGE_LN && FIRST == F_NONE) {
     int rc = BSMS_OK;
     if (launch_edge_bwd<NB>(a, s, rc)) return rc;
     a.ntiles = (int)ceil_div(a.R, 16 * cw);
     if (a.bf16) {
       static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes);
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(battr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve LDS (bf16 build)");
       hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       BSMS_LAUNCH_CHECK();
@@ -1598,6 +1681,16 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
     }
   }
   BSMS_REQUIRE(!a.bf16, BSMS_E_UNSUPPORTED, "chain_bwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
+  if constexpr (NB >= 8) {   // see launch_fwd_t
+    if (a.ntiles <= device_cus()) {
+      static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, false, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve LDS (single-round build)");
+      hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
+      BSMS_LAUNCH_CHECK();
+      return BSMS_OK;
+    }
+  }
   hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
@@ -1621,9 +1714,9 @@ int launch_bwd_n(int gin, int first, const ChainBwdArgs& a, hipStream_t s) {
 #ifdef BSMS_EXPERIMENTS
 extern "C" int bsms_debug_occupancy(int* fwd_blocks_per_cu, int* bwd_blocks_per_cu) {
   hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(fwd_blocks_per_cu, k_chain_fwd<8, IN_EDGE, OUT_LN>,
-                                                                kChainThreads, Ring<8>::lds_bytes);
+                                                                kChainThreads, Ring<8>::lds_bytes(3));
   hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(bwd_blocks_per_cu, k_chain_bwd<8, G_EDGE_LN, F_NONE>,
-                                                                kChainThreads, Ring<8>::lds_bytes);
+                                                                kChainThreads, Ring<8>::lds_bytes(3));
   return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -4;
 }
 #endif
