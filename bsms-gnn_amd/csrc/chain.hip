@@ -1594,7 +1594,7 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
     int rc = BSMS_OK;
     if (launch_edge_fwd<NB>(a, s, rc)) return rc;
   }
-  const int cw = (IN == IN_EDGE) ? kComputeWaves : chain_compute_waves<NB>(a.R);
+  const int cw = (IN == IN_EDGE) ? knob("BSMS_BFEDGE_CW", kComputeWaves) : chain_compute_waves<NB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
   if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
   else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
@@ -1661,7 +1661,7 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
-  const int cw = (GIN == G_EDGE_LN) ? kComputeWaves : chain_compute_waves<NB>(a.R);
+  const int cw = (GIN == G_EDGE_LN) ? knob("BSMS_BFEDGE_CW", kComputeWaves) : chain_compute_waves<NB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
   if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
   else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
