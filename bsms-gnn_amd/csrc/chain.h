@@ -164,7 +164,7 @@ constexpr int kMaxPack = 40;
 // largest |value| it saw into its own entry (blockIdx * 8 + wave; plain stores, no atomics: same-address atomics from
 // ~10^5 waves cost milliseconds), the consumer takes the maximum over the whole array (unused entries are zero: the
 // prepack of the forward call clears all slots of a block).
-constexpr int kBoundWidth = 4096;  // >= 8 x the largest chain grid (2 workgroups per CU)
+constexpr int kBoundWidth = 8192;  // 8 x the largest persistent chain grid (4 workgroups per CU at D <= 64, 256 CUs); beyond that: atomic max on the last entry
 constexpr int kBoundSlots = 32;    // slots of one GMP block / MLP
 struct PackTable {
   int n;

@@ -451,8 +451,11 @@ __device__ __forceinline__ void note_amax(unsigned* brow, int stage, float m, in
 }
 __device__ __forceinline__ void flush_bounds(float* const* slots, int n, const unsigned* brow, int wave, int lane) {
   const int entry = int(blockIdx.x) * 8 + wave;
-  for (int k = 0; k < n; ++k)   // uniform
-    if (slots[k] && lane == 0 && entry < kBoundWidth) slots[k][entry] = __uint_as_float(brow[k]);
+  for (int k = 0; k < n; ++k) {  // uniform
+    if (!slots[k] || lane != 0) continue;
+    if (entry < kBoundWidth - 1) slots[k][entry] = __uint_as_float(brow[k]);
+    else atomicMax(reinterpret_cast<unsigned*>(slots[k]) + (kBoundWidth - 1), brow[k]);   // a part with more CUs than the slot was sized for
+  }
 }
 
 // End of a stage: the accumulators hold sum (s_w W)(s_x x); un-scale by the exact power of two 2^-(k_x + k_w) and add

@@ -139,11 +139,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   int Eg = 139, Ea = 139;
   float sG = 1.f, sA = 1.f;
   if (H2) {   // bound = largest entry of the operand's bound slot (chain.h: kBoundWidth = 4 entries per thread)
-    static_assert(kBoundWidth == 4 * WG_THREADS, "one float4 of each bound slot per thread");
+    static_assert(kBoundWidth == 8 * WG_THREADS, "two float4 of each bound slot per thread");
     __shared__ unsigned bred[2][WG_THREADS / 64];
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-    const u32x4 gv = reinterpret_cast<const u32x4*>(job.g_bound)[tid], av = reinterpret_cast<const u32x4*>(job.a_bound)[tid];
-    unsigned gm = max(max(gv[0], gv[1]), max(gv[2], gv[3])), am = max(max(av[0], av[1]), max(av[2], av[3]));   // non-negative floats order like integers
+    const u32x4* gs = reinterpret_cast<const u32x4*>(job.g_bound);
+    const u32x4* as = reinterpret_cast<const u32x4*>(job.a_bound);
+    const u32x4 gv = gs[tid], gw = gs[tid + WG_THREADS], av = as[tid], aw = as[tid + WG_THREADS];
+    unsigned gm = max(max(max(gv[0], gv[1]), max(gv[2], gv[3])), max(max(gw[0], gw[1]), max(gw[2], gw[3])));   // non-negative floats order like integers
+    unsigned am = max(max(max(av[0], av[1]), max(av[2], av[3])), max(max(aw[0], aw[1]), max(aw[2], aw[3])));
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       gm = max(gm, (unsigned)__shfl_xor((int)gm, o, 64));

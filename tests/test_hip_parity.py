@@ -315,6 +315,86 @@ def test_split_products_are_fp32_accurate(eng):
         assert rel_err(yd.detach().cpu(), y64.float()) < 1e-6
 
 
+def test_gmp_magnitude_range_zero_input_and_many_rows(eng):
+    """The fp16 x 2 arithmetic scales every activation row, weight matrix and (in the weight gradients) operand tensor by a
+    power of two taken from its magnitude (chain.h).  (1) A GMP block whose samples differ by five orders of magnitude and
+    whose weights were rescaled layer by layer must stay as accurate as plain fp32 (three-way against fp64: input
+    gradient and every weight gradient <= 2x the fp32 oracle's distance).  (2) All-zero inputs (every bound is 0) give
+    finite results equal to the oracle's.  (3) A narrow MLP over 70 000 rows uses the persistent grid with four
+    workgroups per CU: every compute wave's entry of the bound slots must be seen (chain.h: kBoundWidth)."""
+    n, e, D, H, p = 180, 1300, 128, 3, 2
+    g = random_graph(n, e, 21)
+    torch.manual_seed(5)
+    ref = ro.GMP(D, H, p)
+    with torch.no_grad():   # weight matrices of very different scale (the per-matrix scale must follow)
+        for k, (name, prm) in enumerate(ref.named_parameters()):
+            if name.endswith("weight"):
+                prm.mul_(10.0 ** ((k % 5) - 2))
+    x = torch.randn(3, n, D) * torch.tensor([1e-3, 1.0, 50.0]).view(3, 1, 1)
+    pos = torch.rand(3, n, p)
+    r = torch.randn(3, n, D) * torch.tensor([1.0, 1e-4, 1e-2]).view(3, 1, 1)
+    def run(dt):
+        m = ro.GMP(D, H, p).to(dt)
+        m.load_state_dict({k: v.to(dt) for k, v in ref.state_dict().items()})
+        xx = x.to(dt).clone().requires_grad_(True)
+        y = m(xx, g, pos.to(dt))
+        (y * r.to(dt)).sum().backward()
+        return y.detach(), xx.grad, {k: q.grad for k, q in m.named_parameters()}
+    y64, gx64, gw64 = run(torch.float64)
+    y32, gx32, gw32 = run(torch.float32)
+    mine = load_sd(eng.GMP(D, H, p), ref.state_dict())
+    xd = dev(x).requires_grad_(True)
+    yd = mine(xd, dev(g), dev(pos))
+    (yd * dev(r)).sum().backward()
+    err = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+    assert err(yd.detach(), y64) <= 2.0 * err(y32, y64) + 1e-7
+    assert err(xd.grad, gx64) <= 2.0 * err(gx32, gx64) + 1e-7
+    for k, q in mine.named_parameters():
+        assert err(q.grad, gw64[k]) <= 2.0 * err(gw32[k], gw64[k]) + 1e-7, (k, err(q.grad, gw64[k]), err(gw32[k], gw64[k]))
+    # (2) zero input (every input bound is 0; with the loss sum(y^2) behind a LayerNorm the gradients are differences of
+    # nearly equal numbers, ~1e-4 from fp64 in ANY fp32 arithmetic): finite, forward equal to the oracle, gradients
+    # three-way like above
+    x = torch.zeros(2, n, D)
+    r = None
+    def run0(dt):
+        m = ro.GMP(D, H, p).to(dt)
+        m.load_state_dict({k: v.to(dt) for k, v in ref.state_dict().items()})
+        xx = x.to(dt).clone().requires_grad_(True)
+        y = m(xx, g, pos[:2].to(dt))
+        y.square().sum().backward()
+        return y.detach(), xx.grad, {k: q.grad for k, q in m.named_parameters()}
+    y64, gx64, gw64 = run0(torch.float64)
+    y32, gx32, gw32 = run0(torch.float32)
+    mine0 = load_sd(eng.GMP(D, H, p), ref.state_dict())
+    x0d = dev(x).requires_grad_(True)
+    y0d = mine0(x0d, dev(g), dev(pos[:2]))
+    y0d.square().sum().backward()
+    assert torch.isfinite(y0d).all() and torch.isfinite(x0d.grad).all()
+    assert err(y0d.detach(), y64) <= 2.0 * err(y32, y64) + 1e-7 and err(x0d.grad, gx64) <= 2.0 * err(gx32, gx64) + 1e-7
+    for k, q in mine0.named_parameters():
+        assert torch.isfinite(q.grad).all() and err(q.grad, gw64[k]) <= 2.0 * err(gw32[k], gw64[k]) + 1e-6, (k, err(q.grad, gw64[k]), err(gw32[k], gw64[k]))
+    # (3) many rows at a narrow width
+    torch.manual_seed(7)
+    R, Dn = 70000, 32
+    refm = ro.MLP(Dn, Dn, Dn, 2, True)
+    xm = torch.randn(R, Dn) * torch.logspace(-3, 2, R).unsqueeze(1)
+    rm = torch.randn(R, Dn)
+    def runm(dt):
+        m = ro.MLP(Dn, Dn, Dn, 2, True).to(dt)
+        m.load_state_dict({k: v.to(dt) for k, v in refm.state_dict().items()})
+        xx = xm.to(dt).clone().requires_grad_(True)
+        (m(xx) * rm.to(dt)).sum().backward()
+        return xx.grad, {k: q.grad for k, q in m.named_parameters()}
+    gx64, gw64 = runm(torch.float64)
+    gx32, gw32 = runm(torch.float32)
+    minem = load_sd(eng.MLP(Dn, Dn, Dn, 2, True), refm.state_dict())
+    xmd = dev(xm).requires_grad_(True)
+    (minem(xmd) * dev(rm)).sum().backward()
+    assert err(xmd.grad, gx64) <= 2.0 * err(gx32, gx64) + 1e-7
+    for k, q in minem.named_parameters():   # 3e-6: 70 000-term fp32 sums in slab order (torch sums pairwise); far inside the 1e-5 parity bar
+        assert err(q.grad, gw64[k]) <= 2.0 * err(gw32[k], gw64[k]) + 3e-6, (k, err(q.grad, gw64[k]), err(gw32[k], gw64[k]))
+
+
 # ------------------------------------------------------------------------------------ A8,A9 BSGMP
 @pytest.mark.parametrize("tag,D,p", [("line11", 32, 3), ("del300", 32, 2), ("del64_d128", 128, 2)])
 def test_bsgmp_golden(eng, graphs, tag, D, p):
