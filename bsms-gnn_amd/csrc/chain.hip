@@ -1091,11 +1091,14 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
   }
 }
 
-// HDR: acc = bias + W act (forward); else acc = W act (backward).  The accumulators start from zero either way.
-template <int NB, int RB, bool SAVE, bool MASK, bool HDR>
+// ZERO / FIN as in mfma_stage: ZERO = the accumulators start from zero (else they continue the raw sums of the previous
+// call: same row scales, pack of the same weight scale); FIN = 0 leave raw sums, 1 un-scale, 2 un-scale + bias.
+// `rs_ext` (nullable): row scales decided by the caller (a Linear over two concatenated sources); else the row maxima of
+// `act` are taken here and noted in the running bounds (`brow`, stage index `stage`).
+template <int NB, int RB, bool SAVE, bool MASK, bool ZERO, int FIN>
 __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, Slot& slot, int lane,
                                          float* store_base, unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB],
-                                         unsigned* brow, int stage) {
+                                         unsigned* brow, int stage, const RowScale* rs_ext = nullptr) {
   using Rg = Ring<NB>;
   constexpr int W = mask_words<NB>();
   constexpr int NSLOT = (NB / 2) * 3 * RB;            // MFMA pairs per chunk
@@ -1107,9 +1110,13 @@ __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act
   unsigned mword[RB][W];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const float m = row_amax<NB>(act[rb]);
-    note_amax(brow, stage, m, lane);
-    rs[rb] = scale_of(m);
+    if (rs_ext) {
+      rs[rb] = rs_ext[rb];
+    } else {
+      const float m = row_amax<NB>(act[rb]);
+      note_amax(brow, stage, m, lane);
+      rs[rb] = scale_of(m);
+    }
     u32x4 h, l;
     split_block<NB>(act[rb], 0, rs[rb].s, h, l);
 #pragma unroll
@@ -1131,8 +1138,8 @@ __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act
     int islot = 0;   // MFMA pair within the chunk
     // one MFMA pair (feature blocks t, t + 1 of row block rb, one plane combination), then the VALU step that rides with it
     auto pair = [&](int t, int rb, const float4& a0, const float4& a1, const unsigned (&piece)[4], bool first) {
-      acc[rb][t] = mma(a0, vec4(piece), (first && c == 0) ? zero : acc[rb][t]);
-      acc[rb][t + 1] = mma(a1, vec4(piece), (first && c == 0) ? zero : acc[rb][t + 1]);
+      acc[rb][t] = mma(a0, vec4(piece), (ZERO && first && c == 0) ? zero : acc[rb][t]);
+      acc[rb][t + 1] = mma(a1, vec4(piece), (ZERO && first && c == 0) ? zero : acc[rb][t + 1]);
       const int s = (islot * NSTEP + NSLOT - 1) / NSLOT;          // the step whose place is this pair, if any
       if (s < NSTEP && s * NSLOT / NSTEP == islot)
         valu_step<NB, RB, SAVE, MASK>(s, c, act, pc, st, rs, mword, store_base, bits_base, off, moff, lane);
@@ -1158,9 +1165,9 @@ __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act
       f0 = n0;
       f1 = n1;
     }
-    if (c == Rg::NCH - 1) {
+    if (FIN != 0 && c == Rg::NCH - 1) {
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) finish_stage<NB, HDR>(acc[rb], rs[rb].E, fw, reinterpret_cast<const float*>(cur), lane);
+      for (int rb = 0; rb < RB; ++rb) finish_stage<NB, FIN == 2>(acc[rb], rs[rb].E, fw, reinterpret_cast<const float*>(cur), lane);
     }
   }
 }
@@ -1286,7 +1293,7 @@ void k_edge_fwd(ChainFwdArgs a) {
     for (int l = 0; l < a.nstage; ++l) {
       float* st_tile = SAVE ? pending + int64_t(tile) * (tile_rows * D) : nullptr;   // uniform
       unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (tile_rows * 4 * mask_words<NB>()) : nullptr;
-      stage_rb<NB, RB, SAVE, true, true>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
+      stage_rb<NB, RB, SAVE, true, true, 2>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
       stamp();
       if (l + 1 < a.nstage) {
 #pragma unroll
@@ -1388,7 +1395,7 @@ void k_edge_bwd(ChainBwdArgs a) {
 #pragma unroll
         for (int w = 0; w < W; ++w)
           mbits[rb][w] = reinterpret_cast<const unsigned*>(a.mask[k] + pad_rows(a.R) * D)[rowc[rb] * (4 * W) + lg * W + w];
-      stage_rb<NB, RB, true, false, false>(acc, g, ring, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff, brow, k);
+      stage_rb<NB, RB, true, false, true, 1>(acc, g, ring, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff, brow, k);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
