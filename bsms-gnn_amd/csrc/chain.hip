@@ -435,13 +435,21 @@ __device__ __forceinline__ float row_amax(const f32x4 (&v)[NB]) {
 // it writes them to its entry of the bound slots.  `m` is a row maximum (>= 0, the same in the four lanes of a row): max
 // over the wave's 16 rows with DPP, then one lane updates the LDS word.  Bit patterns of non-negative floats order like
 // integers (inf / nan rows publish inf / nan: the consumer's results are then inf / nan too, as in the reference).
+__device__ __forceinline__ bool any_slot(float* const (&slots)[kMaxStages + 1]) {
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k <= kMaxStages; ++k) any |= slots[k] != nullptr;
+  return any;
+}
 template <int NB>
-__device__ __forceinline__ unsigned* bound_row(float4* lds, int wave, int lane) {
+__device__ __forceinline__ unsigned* bound_row(float4* lds, int wave, int lane, bool wanted) {
+  if (!wanted) return nullptr;   // uniform
   unsigned* row = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(lds) + Ring<NB>::SIDE_FLOATS) + wave * 16;
   if (lane < 16) row[lane] = 0u;
   return row;
 }
 __device__ __forceinline__ void note_amax(unsigned* brow, int stage, float m, int lane) {
+  if (!brow) return;   // uniform: a launch without bound slots (inference) keeps no running bounds
   int v = __float_as_int(m);
   v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8
   v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
@@ -450,6 +458,7 @@ __device__ __forceinline__ void note_amax(unsigned* brow, int stage, float m, in
   if (lane == 15) brow[stage] = max(brow[stage], unsigned(v));
 }
 __device__ __forceinline__ void flush_bounds(float* const* slots, int n, const unsigned* brow, int wave, int lane) {
+  if (!brow) return;
   const int entry = int(blockIdx.x) * 8 + wave;
   for (int k = 0; k < n; ++k) {  // uniform
     if (!slots[k] || lane != 0) continue;
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   }
   Slot slot{0, a.nring};  // ring slot of the next chunk; runs on across this workgroup's tiles exactly like the loader's
   float4* const ring = lds + Ring<NB>::PRE4;
-  unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
+  unsigned* brow = bound_row<NB>(lds, wave, lane, any_slot(a.amax));   // this wave's running magnitude bounds
   // Persistent workgroups: the grid is sized to what the chip holds at once and strides over the tiles, so a CU
   // never waits for the dispatcher to refill a slot (measured: 20-35 % of slot time was empty with one
   // workgroup per tile) and the loader is already fetching the next tile's first chunk during this epilogue.
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   }
   Slot slot{0, a.nring};  // ring slot of the next chunk, across this workgroup's tiles
   float4* const ring = lds + Ring<NB>::PRE4;
-  unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
+  unsigned* brow = bound_row<NB>(lds, wave, lane, any_slot(a.gmax));   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {  // persistent workgroups (see k_chain_fwd)
   const int64_t row = int64_t(tile) * (16 * cw) + wave * 16 + (lane & 15);
   const bool live = row < a.R;
@@ -1220,7 +1229,7 @@ void k_edge_fwd(ChainFwdArgs a) {
   const float* w0t = reinterpret_cast<const float*>(lds);   // fiber weights (LDS side table, see k_chain_fwd)
   Slot slot{0, a.nring};
   float4* const ring = lds + Ring<NB>::PRE4;
-  unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
+  unsigned* brow = bound_row<NB>(lds, wave, lane, any_slot(a.amax));   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int64_t row[RB];
     PairOff off[RB];
@@ -1353,7 +1362,7 @@ void k_edge_bwd(ChainBwdArgs a) {
   fetch_targets(blockIdx.x, nnode);
   Slot slot{0, a.nring};
   float4* const ring = lds + Ring<NB>::PRE4;
-  unsigned* brow = bound_row<NB>(lds, wave, lane);   // this wave's running magnitude bounds
+  unsigned* brow = bound_row<NB>(lds, wave, lane, any_slot(a.gmax));   // this wave's running magnitude bounds
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int64_t row[RB], rowc[RB];
     PairOff off[RB];

@@ -7,6 +7,8 @@
 #include <numeric>
 #include <vector>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace bsms {
@@ -31,9 +33,14 @@ int side_lane(SideLane** out, int which) {
   SideLane& l = g_lanes[dev][which];
   if (!l.stream) {
     BSMS_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-    BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.fork_ev, hipEventDisableTiming));
-    BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.join_ev, hipEventDisableTiming));
-    for (int k = 0; k < 2; ++k) BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.done_ev[k], hipEventDisableTiming));
+    // same-device stream ordering only: no timing, and no system-scope fence when an event completes (the kernels'
+    // own end-of-kernel release / start-of-kernel acquire make their data visible device-wide; the extra fence is for
+    // hosts and other devices reading behind the event, which nothing here does)
+    unsigned flags = hipEventDisableTiming;
+    if (!getenv("BSMS_EVENT_SYSTEM_FENCE")) flags |= hipEventDisableSystemFence;
+    BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.fork_ev, flags));
+    BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.join_ev, flags));
+    for (int k = 0; k < 2; ++k) BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.done_ev[k], flags));
   }
   *out = &l;
   return BSMS_OK;
