@@ -32,12 +32,14 @@ int side_lane(SideLane** out, int which) {
   std::lock_guard<std::mutex> lock(g_lane_mu);
   SideLane& l = g_lanes[dev][which];
   if (!l.stream) {
-    BSMS_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    BSMS_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));   // (a lower or higher stream priority for the lanes: +-0, profiles/README.md)
     // same-device stream ordering only: no timing, and no system-scope fence when an event completes (the kernels'
     // own end-of-kernel release / start-of-kernel acquire make their data visible device-wide; the extra fence is for
     // hosts and other devices reading behind the event, which nothing here does)
-    unsigned flags = hipEventDisableTiming;
-    if (!getenv("BSMS_EVENT_SYSTEM_FENCE")) flags |= hipEventDisableSystemFence;
+    unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
+#ifdef BSMS_EXPERIMENTS
+    if (getenv("BSMS_EVENT_SYSTEM_FENCE")) flags = hipEventDisableTiming;   // A/B: 179.7 (with the fence) vs 182.0 steps/s
+#endif
     BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.fork_ev, flags));
     BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.join_ev, flags));
     for (int k = 0; k < 2; ++k) BSMS_HIP_CHECK(hipEventCreateWithFlags(&l.done_ev[k], flags));
