@@ -1107,7 +1107,8 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
 template <int NB, int RB, bool SAVE, bool MASK, bool ZERO, int FIN>
 __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, Slot& slot, int lane,
                                          float* store_base, unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB],
-                                         unsigned* brow, int stage, const RowScale* rs_ext = nullptr) {
+                                         unsigned* brow, int stage, const RowScale* rs_ext = nullptr,
+                                         unsigned long long* waited = nullptr) {   // experiments: cycles at the chunk barriers
   using Rg = Ring<NB>;
   constexpr int W = mask_words<NB>();
   constexpr int NSLOT = (NB / 2) * 3 * RB;            // MFMA pairs per chunk
@@ -1137,6 +1138,13 @@ __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < Rg::NCH; ++c) {
+#ifdef BSMS_EXPERIMENTS
+    if (waited) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      lds_barrier();
+      *waited += __builtin_amdgcn_s_memtime() - t0;
+    } else
+#endif
     lds_barrier();                                         // chunk has landed (and my reads of the last one are done)
     const float4* cur = lds + slot.i * Rg::CH4;
     if (++slot.i == slot.nr) slot.i = 0;
@@ -1238,6 +1246,7 @@ void k_edge_fwd(ChainFwdArgs a) {
     float pi[RB][7], pj[RB][7];
 #ifdef BSMS_EXPERIMENTS
     int stamp_i = 0;
+    unsigned long long waited = 0;
     auto stamp = [&]() { if (a.timing && tid == 0 && stamp_i < 16) a.timing[int64_t(tile) * 16 + stamp_i++] = __builtin_amdgcn_s_memtime(); };
 #else
     auto stamp = [] {};
@@ -1302,7 +1311,11 @@ void k_edge_fwd(ChainFwdArgs a) {
     for (int l = 0; l < a.nstage; ++l) {
       float* st_tile = SAVE ? pending + int64_t(tile) * (tile_rows * D) : nullptr;   // uniform
       unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (tile_rows * 4 * mask_words<NB>()) : nullptr;
+#ifdef BSMS_EXPERIMENTS
+      stage_rb<NB, RB, SAVE, true, true, 2>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l, nullptr, a.timing ? &waited : nullptr);
+#else
       stage_rb<NB, RB, SAVE, true, true, 2>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
+#endif
       stamp();
       if (l + 1 < a.nstage) {
 #pragma unroll
@@ -1334,6 +1347,9 @@ void k_edge_fwd(ChainFwdArgs a) {
       store_rows<NB, false>(acc[rb], a.y, roff, lg, a.out_mode);
     }
     stamp();
+#ifdef BSMS_EXPERIMENTS
+    if (a.timing && tid == 0) a.timing[int64_t(tile) * 16 + 11] = waited;
+#endif
   }
   if (SAVE) flush_bounds(a.amax, kMaxStages + 1, brow, wave, lane);
 }
@@ -1527,9 +1543,9 @@ template <int NB, int PL = kPL>
 int max_ring() { return (int)std::min<size_t>(6, (size_t(160) * 1024 - Ring<NB, PL>::PRE_FLOATS * sizeof(float)) / (Ring<NB, PL>::CHF * sizeof(float))); }
 template <int NB, int PL = kPL>
 void pick_stream(int64_t ntiles, int cw, int nload_default, int& nload, int& nring) {
-  static const int deep = knob("BSMS_RING_DEEP", 6), lone_nl = knob("BSMS_LONE_NL", 2);
+  static const int deep = knob("BSMS_RING_DEEP", 6), lone_nl = knob("BSMS_LONE_NL", 2), shared = knob("BSMS_RING", 3);
   nload = std::max(1, std::min(nload_default, 8 - cw));
-  nring = 3;
+  nring = std::min(shared, max_ring<NB, PL>());
   if (ntiles <= device_cus()) {
     nload = std::max(nload, std::min(lone_nl, 8 - cw));
     nring = std::min(deep, max_ring<NB, PL>());
