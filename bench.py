@@ -307,22 +307,25 @@ def optimizer_step_time(dp, iters=20):
     return {"avg_us": ms * 1e3, "what": "clip_grad_norm_(1.0) + AdamW over all trainable parameters, fused (2 launches)"}
 
 
-def rollout_rate(sim, wl, steps=60):
+def rollout_rate(sim, wl, steps=200):
     """Secondary figure: forward-only autoregressive rollout, batch 1 like the reference
-    (rollout.py:48), inference mode; eager launches vs one captured HIP graph per step."""
-    import bsms_gnn_amd as eng
+    (rollout.py:48), inference mode; eager launches vs replay of one captured HIP graph per step (capture excluded)."""
+    from bsms_gnn_amd.rollout import _Stepper
     c = wl["cfg"]["out_dim"]
     ic, mask = wl["node_in"][:1].contiguous(), wl["mask"][:1].contiguous()
     g1, i1 = [g[:1] for g in wl["m_gs"]], [i[:1] for i in wl["m_ids"]]
     out = {"batch": 1, "steps": steps, "unit": "rollout steps/s (forward only)"}
-    for name, use_graph in (("eager", False), ("hip_graph", True)):
-        res = torch.zeros(steps, ic.shape[1], c, device="cuda")
-        eng.rollout_one_traj(sim, ic, res[:3], mask, g1, i1, use_graph=use_graph)       # warm-up (+ capture)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.rollout_one_traj(sim, ic, res, mask, g1, i1, use_graph=use_graph)
-        torch.cuda.synchronize()
-        out[name] = steps / (time.perf_counter() - t0)
+    with torch.no_grad():
+        for name, use_graph in (("eager", False), ("hip_graph", True)):
+            st = _Stepper(sim, ic, mask, g1, i1, c, use_graph)
+            for _ in range(5):
+                st.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                st.step()
+            torch.cuda.synchronize()
+            out[name] = steps / (time.perf_counter() - t0)
     return out
 
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     "bsms_mlp_saved_bytes": (c_size_t, [c_i64, c_i64, c_i64, c_i64, c_int]),
     "bsms_mlp_work_bytes": (c_size_t, [c_i64, c_i64, c_i64, c_i64, c_int]),
     "bsms_mlp_fwd": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, PP, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bsms_mlp_fwd_ex": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "bsms_mlp_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, PP, c_void_p, c_void_p,
                              c_void_p, PP, c_void_p]),
     "bsms_mlp_bwd_ex": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, PP, c_void_p, c_void_p,

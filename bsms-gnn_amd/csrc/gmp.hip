@@ -545,6 +545,11 @@ extern "C" size_t bsms_mlp_work_bytes(int64_t R, int64_t in_dim, int64_t D, int6
 
 extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int H, int layer_norm,
                             const float* const* params, float* y, void* saved, void* work, bsms_stream_t stream) {
+  return bsms_mlp_fwd_ex(x, R, in_dim, D, out_dim, H, layer_norm, params, y, saved, work, 0, stream);
+}
+
+extern "C" int bsms_mlp_fwd_ex(const float* x, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int H, int layer_norm,
+                               const float* const* params, float* y, void* saved, void* work, int flags, bsms_stream_t stream) {
   int rc = check_mlp(R, in_dim, D, out_dim, H, layer_norm, "mlp_fwd");
   if (rc) return rc;
   BSMS_REQUIRE((x && y) || R == 0, BSMS_E_INVALID_ARG, "mlp_fwd: null argument");
@@ -563,7 +568,8 @@ extern "C" int bsms_mlp_fwd(const float* x, int64_t R, int64_t in_dim, int64_t D
     if (training) add_pack(t, params[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.wt[l]);
   }
   t.zero = training ? sv.bound : nullptr;
-  if ((rc = launch_prepack(t, s))) return rc;
+  BSMS_REQUIRE(!(flags & BSMS_MLP_REUSE_PACKS) || !training, BSMS_E_INVALID_ARG, "mlp_fwd: BSMS_MLP_REUSE_PACKS is an inference flag (saved must be NULL)");
+  if (!(flags & BSMS_MLP_REUSE_PACKS) && (rc = launch_prepack(t, s))) return rc;
 
   ChainFwdArgs a{};
   a.R = R; a.x = x;

@@ -147,9 +147,9 @@ class BSMS_Simulator(nn.Module):
         pos = torch.empty(B, N, p, device=node_in.device, dtype=torch.float32)
         _abi.check(L.bsms_sim_prologue(node_in.data_ptr(), R, C, p, ni._E_data.data_ptr(), ni._E_data_squared.data_ptr(),
                                        ni.std_eps.data_ptr(), norm_in.data_ptr(), pos.data_ptr(), s), "bsms_sim_prologue")
-        x = self.encode(norm_in)
+        x = self.encode(norm_in, session=None if session is None else session.encode)
         x = self.process(x, m_ids, m_gs, pos, session=session)
-        y = self.decode(x)
+        y = self.decode(x, session=None if session is None else session.decode)
         pred = torch.empty(B, N, C, device=node_in.device, dtype=torch.float32)
         _abi.check(L.bsms_sim_epilogue(y.data_ptr(), node_in.data_ptr(), mask.data_ptr(), None, R, C, p, no._E_data.data_ptr(),
                                        no._E_data_squared.data_ptr(), no.std_eps.data_ptr(), pred.data_ptr(),

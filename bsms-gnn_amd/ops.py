@@ -151,17 +151,46 @@ def _needs_grad(*tensors):
 
 
 # ------------------------------------------------------------------------------------------ MLP
-def _mlp_infer(x, hidden, layer_norm, out_dim, params):
-    """Forward only (`saved` = NULL at the ABI): nothing is written for a backward."""
+def _mlp_infer(x, hidden, layer_norm, out_dim, params, session=None):
+    """Forward only (`saved` = NULL at the ABI): nothing is written for a backward.  `session` (MLPSession): a caller that
+    applies the same MLP again and again keeps a private work buffer; the weight packs in it are reused while the
+    parameters are unchanged (BSMS_MLP_REUSE_PACKS)."""
     R, in_dim = x.shape
     D = params[0].shape[0]
     L = _abi.lib()
     y = torch.empty(R, out_dim, device=x.device, dtype=x.dtype)
-    work = _workspace(x.device, L.bsms_mlp_work_bytes(R, in_dim, D, out_dim, hidden))
+    nbytes = L.bsms_mlp_work_bytes(R, in_dim, D, out_dim, hidden)
+    flags = 0
+    if session is not None:
+        flags = session.flags(params, (R, in_dim, D, out_dim, hidden, int(layer_norm)), nbytes, x.device)
+        work = session.work
+    else:
+        work = _workspace(x.device, nbytes)
     pp, keep = _param_ptrs(params)
-    _abi.check(L.bsms_mlp_fwd(x.data_ptr(), R, in_dim, D, out_dim, hidden, int(layer_norm), pp, y.data_ptr(), None,
-                              work.data_ptr(), _stream()), "bsms_mlp_fwd(inference)")
+    _abi.check(L.bsms_mlp_fwd_ex(x.data_ptr(), R, in_dim, D, out_dim, hidden, int(layer_norm), pp, y.data_ptr(), None,
+                                 work.data_ptr(), flags, _stream()), "bsms_mlp_fwd(inference)")
     return y
+
+
+class MLPSession:
+    """Private work buffer + pack validity key of an MLP applied repeatedly in inference (the encoder / decoder of a
+    rollout).  Same validity rules as InferenceSession: parameter pointers, autograd versions and the engine's parameter
+    epoch (raw-pointer optimizer updates)."""
+
+    def __init__(self):
+        self.work, self.key = None, None
+
+    def invalidate(self):
+        self.key = None
+
+    def flags(self, params, geom, nbytes, device):
+        if self.work is None or self.work.numel() < nbytes or self.work.device != device:
+            self.work = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.key = None
+        key = (_PARAM_EPOCH[0], tuple((q.data_ptr(), q._version) for q in params), tuple(geom))
+        reuse = 1 if key == self.key else 0       # BSMS_MLP_REUSE_PACKS
+        self.key = key
+        return reuse
 
 
 class _MLPFunction(torch.autograd.Function):
@@ -224,7 +253,7 @@ class MLP(nn.Module):
                 out += [m.weight, m.bias]
         return out
 
-    def forward(self, x):
+    def forward(self, x, session=None):
         x = _dev_f32(x, "MLP")
         lead = x.shape[:-1]
         params = self.flat_params()
@@ -232,7 +261,7 @@ class MLP(nn.Module):
         if _needs_grad(x, *params):
             y = _MLPFunction.apply(x2, self.hidden_layers, self.layer_normalized, self.output_dim, *params)
         else:
-            y = _mlp_infer(x2, self.hidden_layers, self.layer_normalized, self.output_dim, params)
+            y = _mlp_infer(x2, self.hidden_layers, self.layer_normalized, self.output_dim, params, session)
         return y.view(*lead, self.output_dim)
 
 
@@ -522,9 +551,12 @@ class InferenceSession:
 
     def __init__(self, static_pos=False):
         self.static_pos, self.work, self.pkey, self.gkey = static_pos, None, None, None
+        self.encode, self.decode = MLPSession(), MLPSession()    # the encoder / decoder around the U-Net (models/model.py:103-105)
 
     def invalidate(self):
         self.pkey = self.gkey = None
+        self.encode.invalidate()
+        self.decode.invalidate()
 
     def flags(self, params, plans, B, nbytes, device, geom=()):
         if self.work is None or self.work.numel() < nbytes or self.work.device != device:

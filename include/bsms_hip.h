@@ -141,6 +141,14 @@ int bsms_mlp_bwd(const float* x, const float* grad_y, int64_t R, int64_t in_dim,
                  int64_t out_dim, int hidden, int layer_norm, const float* const* params,
                  const void* saved, void* work, float* grad_x /* nullable */,
                  float* const* grads, bsms_stream_t stream);
+/* bsms_mlp_fwd with `flags`.  BSMS_MLP_REUSE_PACKS (inference only, saved = NULL): the weight packs written into `work` by
+ * the previous bsms_mlp_fwd / _ex call with the same shape and the same parameter VALUES are still there (a private
+ * `work` buffer of an autoregressive caller: utils/rollout_utils.py:49-62 applies the same encoder / decoder every
+ * step) -- the prepack launches are skipped. */
+enum { BSMS_MLP_REUSE_PACKS = 1 };
+int bsms_mlp_fwd_ex(const float* x, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int hidden,
+                    int layer_norm, const float* const* params, float* y, void* saved, void* work,
+                    int flags, bsms_stream_t stream);
 
 /* ---------------------------------------------------------------- A4: GMP block -------------
  * GMP.forward (ops/basic.py:48-98) incl. both MLPs, the gathers, the fiber [pos_i-pos_j, |.|]
