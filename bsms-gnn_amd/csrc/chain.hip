@@ -66,14 +66,6 @@ __device__ __forceinline__ RowScale scale_of(float amax, int emin = 12) {
   return RowScale{__uint_as_float(unsigned(266 - E) << 23), E};
 }
 
-// exact three-way bf16 split by truncation (rounds 1-2; still the arithmetic of the weight-gradient kernel, wgrad.hip)
-__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(hi);
-  mid = __float_as_uint(r1) & 0xffff0000u;
-  lo = __float_as_uint(r1 - __uint_as_float(mid));  // <= 8 significant bits left: already a bf16
-}
-
 // FRAG packs (layout in chain.h): per 32-feature K block c a chunk of kChunkHdrFloats + NB * 256 * planes dwords;
 //   body dword ((t*planes + plane)*64 + lane)*4 + v  =  16-bit pair (slots 2v, 2v+1) of plane `plane` of
 //   M[16 t + (lane & 15)][16 (2c + (i >> 2)) + 4 (lane >> 4) + (i & 3)],  i = slot

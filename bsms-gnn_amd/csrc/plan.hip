@@ -84,7 +84,7 @@ int side_wait_mark(SideLane* lane, int slot, hipStream_t main) {
 
 using namespace bsms;
 
-extern "C" int bsms_abi_version(void) { return 2; }  // 2: saved == NULL selects inference in *_fwd
+extern "C" int bsms_abi_version(void) { return 3; }  // 2: saved == NULL selects inference in *_fwd; 3: bsms_mlp_fwd_ex, larger saved buffers (bound slots)
 extern "C" const char* bsms_last_error(void) { return bsms::g_err; }
 
 namespace {

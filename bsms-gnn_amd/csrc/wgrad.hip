@@ -5,11 +5,11 @@
 //   H2   both operands come with a magnitude bound: fp16 x 2 pieces with one power-of-two scale per TENSOR (the
 //        reduction index is the row, so the chain kernels' per-row scales cannot be used) and three partial products
 //        h l + l h + h h per fragment pair -- the arithmetic of the chain kernels (chain.h);
-//   BF3  no bounds: the exact three-way bf16 split of rounds 1-2, six partial products (needs no range information).  A workgroup owns one 128x128 block of dW and a
-// contiguous slab of rows, 32 rows per chunk:
+//   BF3  no bounds: the exact three-way bf16 split of rounds 1-2, six partial products (needs no range information).
+// A workgroup owns one 128x128 block of dW and a contiguous slab of rows, 32 rows per chunk:
 //   stage   1024 threads load the chunk of G and of A row-major (16-byte loads, full 512-byte row bursts, three
-//           chunks ahead in registers), split every value into its hi/mid/lo bf16 and store three row-major bf16 planes per
-//           matrix (row pitch 288 B so that 8 consecutive rows hit disjoint banks);
+//           chunks ahead in registers), split every value into its 16-bit pieces (H2: h, l; BF3: hi, mid, lo) and store
+//           one row-major plane per piece and matrix (row pitch 288 B so that 8 consecutive rows hit disjoint banks);
 //   MFMA    the reduction index (rows) is the MFMA's K, i.e. an operand fragment is a COLUMN of 8 rows per lane:
 //           ds_read_b64_tr_b16 delivers exactly that from the row-major planes (a 16-lane group transposes a
 //           4-row x 16-column block), two reads per fragment, no bank conflicts.
