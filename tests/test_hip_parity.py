@@ -395,6 +395,48 @@ def test_gmp_magnitude_range_zero_input_and_many_rows(eng):
         assert err(q.grad, gw64[k]) <= 2.0 * err(gw32[k], gw64[k]) + 3e-6, (k, err(q.grad, gw64[k]), err(gw32[k], gw64[k]))
 
 
+@pytest.mark.parametrize("n,e,B", [(40, 90, 1), (300, 2300, 3), (900, 7000, 5), (2000, 16000, 4), (1200, 9000, 7)])
+def test_gmp_launch_shapes(eng, n, e, B):
+    """The chain launchers pick tile shapes by row count: 16-row blocks per wave (one or two), 4-7 compute waves, one or
+    several rounds of workgroups, the single-round kernel variants, 3-6 ring slots, 1-2 loader waves (chain.hip:
+    pick_stream, launch_edge_fwd / _bwd, chain_compute_waves).  Edge-row counts from 90 to 64 000 at D = 128 walk through
+    all of them (35 000 rows: two row blocks per wave in the forward; 63 000 / 64 000: several rounds).
+    Forward: three-way against fp64 (<= 3x the fp32 oracle's distance).  Gradients: at these sizes a few of the 10^6-10^7
+    ReLU inputs lie within 1e-8 of zero (checked: 1.1e-8 for the second case), so any two fp32 arithmetics disagree on a
+    handful of ReLU masks -- one flipped mask moves two node rows of the input gradient by ~1e-2 and the edge-MLP weight
+    gradients by ~1e-3 (conftest.KinkMargin) -- whereas a wrong tile would corrupt whole 16-row blocks.  Hence: all but
+    at most max(4, 0.2 %) node rows of the input gradient within 1e-5 of the gradient scale, every weight gradient within
+    5e-3, the median over the weight tensors within 3e-5."""
+    D, H, p = 128, 3, 2
+    g = random_graph(n, e, 100 + n)
+    torch.manual_seed(n)
+    ref = ro.GMP(D, H, p)
+    x, pos, r = torch.randn(B, n, D), torch.rand(B, n, p), torch.randn(B, n, D)
+    def run(dt):
+        m = ro.GMP(D, H, p).to(dt)
+        m.load_state_dict({k: v.to(dt) for k, v in ref.state_dict().items()})
+        xx = x.to(dt).clone().requires_grad_(True)
+        y = m(xx, g, pos.to(dt))
+        (y * r.to(dt)).sum().backward()
+        return y.detach(), xx.grad, {k: q.grad for k, q in m.named_parameters()}
+    y64, gx64, gw64 = run(torch.float64)
+    y32, _, _ = run(torch.float32)
+    mine = load_sd(eng.GMP(D, H, p), ref.state_dict())
+    xd = dev(x).requires_grad_(True)
+    yd = mine(xd, dev(g), dev(pos))
+    (yd * dev(r)).sum().backward()
+    err = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+    assert err(yd.detach(), y64) <= 3.0 * err(y32, y64) + 2e-6
+    row_err = (xd.grad.double().cpu() - gx64).abs().amax(-1).reshape(-1) / float(gx64.abs().max())
+    outliers = int((row_err > 1e-5).sum())
+    assert outliers <= max(4, B * n // 500), (outliers, float(row_err.max()))
+    errs = {k: err(q.grad, gw64[k]) for k, q in mine.named_parameters()}
+    assert max(errs.values()) < 5e-3, errs
+    assert sorted(errs.values())[len(errs) // 2] < 3e-5, errs
+    with torch.no_grad():   # the inference variants (no activation stores, no bounds) give the same forward
+        assert torch.equal(mine(dev(x), dev(g), dev(pos)), yd.detach())
+
+
 # ------------------------------------------------------------------------------------ A8,A9 BSGMP
 @pytest.mark.parametrize("tag,D,p", [("line11", 32, 3), ("del300", 32, 2), ("del64_d128", 128, 2)])
 def test_bsgmp_golden(eng, graphs, tag, D, p):
