@@ -259,6 +259,13 @@ def roofline_objects(wl, batch, dtype="f32"):
     agg_warm = lambda: launch(0)
     ms = time_kernel(agg_cold, iters=60)
     ms_warm = time_kernel(agg_warm)
+    # what the chip delivers on a plain device copy under the SAME cold rotation (read one message buffer, write another):
+    # the practical ceiling for cold streams of this size, reported next to the claim (the claim stays against 8 TB/s)
+    def copy_cold():
+        i = state["i"] = (state["i"] + 1) % nbuf
+        msgs[i].copy_(msgs[(i + nbuf // 2) % nbuf])
+    ms_copy = time_kernel(copy_cold, iters=30)
+    copy_gbs = 2 * batch * e0 * D * s / (ms_copy * 1e-3) / 1e9
     del msgs, outs
     traffic, in_step = None, None
     try:   # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/*_traffic.json)
@@ -279,7 +286,10 @@ def roofline_objects(wl, batch, dtype="f32"):
             "method": f"cold: {nbuf} rotating message buffers ({nbuf * batch * e0 * D * s / 2**20:.0f} MiB > 256 MiB memory-side cache), "
                       "one HIP event pair per launch on the launching stream",
             "frac_cold": gbs(ms) / HBM_PEAK_GBS, "frac_warm": gbs(ms_warm) / HBM_PEAK_GBS, "avg_us_warm": ms_warm * 1e3,
-            "frac_in_step": None if not in_step else in_step.get("frac"), "in_step": in_step}
+            "frac_in_step": None if not in_step else in_step.get("frac"), "in_step": in_step,
+            "cold_device_copy": {"GBps": copy_gbs, "frac_of_peak": copy_gbs / HBM_PEAK_GBS,
+                                 "what": "torch copy_ of one message buffer into another under the same rotation (read + write bytes)",
+                                 "aggregation_vs_copy": gbs(ms) / copy_gbs}}
     # edge-MLP forward through a GMP at L0: flops of the three D x D Linears per edge row
     if bf:
         return roof, None
