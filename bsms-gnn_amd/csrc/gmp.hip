@@ -368,6 +368,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       a.gstore[k + 1] = wk.gE[H - k - 1];
     }
     if (!bf) for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(16 + k) * kBoundWidth;
+    else a.gmax[H] = sv.bound + size_t(16 + H) * kBoundWidth;   // bf16 precision: only gE[0] (fp32 scatter sums dPs / dPd feed fp32 weight-gradient jobs)
     if ((rc = launch_chain_bwd((int)D, G_EDGE_LN, F_NONE, a, s))) return rc;
   }
   // From here two independent strands run CONCURRENTLY (fork/join on an internal side stream):
@@ -448,7 +449,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     auto set = [&](WgradJob& j, const float* G, int col0) {
       j.G = G; j.A = x; j.dW = ge[0]; j.db = nullptr; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldE0; j.col0 = col0; j.bf16 = 0;
       // dPs / dPd are sums of at most max-degree rows of gE[0]; x is covered by the joint bound of the node chain's input
-      if (!bf) { j.g_bound = sv.bound + size_t(16 + H) * kBoundWidth; j.a_bound = sv.bound + size_t(8) * kBoundWidth; j.a_mul = 1.f; }
+      j.g_bound = sv.bound + size_t(16 + H) * kBoundWidth; j.a_bound = sv.bound + size_t(8) * kBoundWidth; j.a_mul = 1.f;
     };
     set(jobs[0], wk.dPs, int(p + 1));
     set(jobs[1], wk.dPd, int(p + 1 + D));
