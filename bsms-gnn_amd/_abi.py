@@ -17,6 +17,7 @@ SIGNATURES = {
     "bsms_plan_create": (c_int, [c_void_p, c_i64, c_i64, PP]),
     "bsms_plan_set_pool": (c_int, [c_void_p, c_void_p, c_i64]),
     "bsms_plan_destroy": (c_int, [c_void_p]),
+    "bsms_plan_pool_trim": (c_int, []),
     "bsms_plan_num_nodes": (c_i64, [c_void_p]),
     "bsms_plan_num_edges": (c_i64, [c_void_p]),
     "bsms_plan_num_pooled": (c_i64, [c_void_p]),

@@ -96,4 +96,6 @@ struct bsms_plan {
   int32_t *rowptr = nullptr, *src = nullptr, *dst = nullptr, *perm = nullptr;
   int32_t *t_rowptr = nullptr, *t_dst = nullptr, *t_eid = nullptr, *t_pos = nullptr;
   int32_t *ids = nullptr, *inv = nullptr;
+  int32_t *block = nullptr, *pool_block = nullptr;   // the two device allocations the pointers above point into
+  size_t block_cap = 0, pool_cap = 0;                // their capacities in bytes (plan.hip recycles them)
 };

@@ -88,13 +88,75 @@ extern "C" int bsms_abi_version(void) { return 3; }  // 2: saved == NULL selects
 extern "C" const char* bsms_last_error(void) { return bsms::g_err; }
 
 namespace {
-int upload(int32_t** dev, const std::vector<int32_t>& host) {
-  size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(int32_t);
-  BSMS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(dev), bytes));
-  if (!host.empty())
-    BSMS_HIP_CHECK(hipMemcpy(*dev, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+// Index uploads go through a private non-blocking stream: a plain hipMemcpy is ordered behind everything the caller has
+// queued on the NULL stream (PyTorch's default), i.e. building the plans of a NEW mesh would drain the GPU first.  The
+// copy is complete on the host's timeline when upload_block returns, so kernels launched afterwards on any stream see it.
+hipStream_t upload_stream() {
+  static hipStream_t s = [] {
+    hipStream_t x = nullptr;
+    if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) x = nullptr;
+    return x;
+  }();
+  return s;
+}
+// Device blocks of destroyed plans are kept for the next plan: hipFree waits for the whole device, and a variable-mesh
+// training run retires L + 1 plans per step once the host-side cache is full.  (bsms_plan_destroy's contract: nothing that
+// uses the plan is still in flight -- the recycled block is overwritten by the next upload without further ordering.)
+struct PoolBlock { size_t cap; int32_t* ptr; };
+std::mutex g_pool_mu;
+std::vector<PoolBlock> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t kPoolMaxBytes = size_t(512) << 20, kPoolMaxBlocks = 512, kBlockGrain = size_t(64) << 10;
+
+int alloc_block(int32_t** dev, size_t bytes, size_t* cap) {
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i)
+      if (g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + kBlockGrain && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
+    if (best >= 0) {
+      *dev = g_pool[best].ptr;
+      *cap = g_pool[best].cap;
+      g_pool_bytes -= g_pool[best].cap;
+      g_pool.erase(g_pool.begin() + best);
+      return BSMS_OK;
+    }
+  }
+  *cap = (bytes + bytes / 8 + kBlockGrain - 1) / kBlockGrain * kBlockGrain;   // headroom: the next batch's level is rarely the same size
+  BSMS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(dev), *cap));
   return BSMS_OK;
 }
+void release_block(int32_t* ptr, size_t cap) {
+  if (!ptr) return;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (g_pool.size() < kPoolMaxBlocks && g_pool_bytes + cap <= kPoolMaxBytes) {
+      g_pool.push_back(PoolBlock{cap, ptr});
+      g_pool_bytes += cap;
+      return;
+    }
+  }
+  (void)hipFree(ptr);
+}
+
+// ONE allocation and ONE copy per plan (ten of each cost ~1 ms per level; a variable-mesh batch builds L + 1 plans per step)
+int upload_block(int32_t** dev, size_t* cap, const std::vector<int32_t>& host) {
+  const size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(int32_t);
+  int rc = alloc_block(dev, bytes, cap);
+  if (rc) return rc;
+  if (!host.empty()) {
+    hipStream_t us = upload_stream();
+    if (us) {
+      BSMS_HIP_CHECK(hipMemcpyAsync(*dev, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, us));
+      BSMS_HIP_CHECK(hipStreamSynchronize(us));
+    } else {
+      BSMS_HIP_CHECK(hipMemcpy(*dev, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+  }
+  return BSMS_OK;
+}
+constexpr size_t kIdxAlign = 64;   // int32 elements (256 bytes) between the arrays of a block
+inline size_t idx_pad(size_t n) { return (n + kIdxAlign - 1) / kIdxAlign * kIdxAlign; }
 }  // namespace
 
 extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_plan_t** out) {
@@ -111,7 +173,11 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
                  "plan_create: edge %lld = (%lld -> %lld) out of range for N=%lld", (long long)e,
                  (long long)gi[e], (long long)gj[e], (long long)N);
 
-  std::vector<int32_t> rowptr(N + 1, 0), t_rowptr(N + 1, 0);
+  // all eight index arrays in one host block (layout = the device block)
+  const size_t nN = idx_pad(size_t(N) + 1), nE = idx_pad(size_t(E));
+  std::vector<int32_t> blk(2 * nN + 6 * nE, 0);
+  int32_t *rowptr = blk.data(), *t_rowptr = rowptr + nN, *src = t_rowptr + nN, *dst = src + nE, *perm = dst + nE,
+          *t_dst = perm + nE, *t_eid = t_dst + nE, *t_pos = t_eid + nE;
   for (int64_t e = 0; e < E; ++e) {
     rowptr[gj[e] + 1]++;
     t_rowptr[gi[e] + 1]++;
@@ -124,13 +190,13 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
   }
   if (N == 0) min_deg = 0;
   for (int64_t e = 0; e < E; ++e) max_src = std::max(max_src, gi[e]);
-  std::partial_sum(rowptr.begin(), rowptr.end(), rowptr.begin());
-  std::partial_sum(t_rowptr.begin(), t_rowptr.end(), t_rowptr.begin());
+  std::partial_sum(rowptr, rowptr + N + 1, rowptr);
+  std::partial_sum(t_rowptr, t_rowptr + N + 1, t_rowptr);
 
   // stable counting sorts: slots of equal key keep the caller's edge order
-  std::vector<int32_t> src(E), dst(E), perm(E), slot_of_edge(E);
+  std::vector<int32_t> slot_of_edge(E);
   {
-    std::vector<int32_t> cur(rowptr.begin(), rowptr.end() - 1);
+    std::vector<int32_t> cur(rowptr, rowptr + N);
     for (int64_t e = 0; e < E; ++e) {
       int32_t q = cur[gj[e]]++;
       src[q] = (int32_t)gi[e];
@@ -139,9 +205,8 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
       slot_of_edge[e] = q;
     }
   }
-  std::vector<int32_t> t_dst(E), t_eid(E), t_pos(E);
   {
-    std::vector<int32_t> cur(t_rowptr.begin(), t_rowptr.end() - 1);
+    std::vector<int32_t> cur(t_rowptr, t_rowptr + N);
     for (int64_t e = 0; e < E; ++e) {
       int32_t t = cur[gi[e]]++;
       t_dst[t] = (int32_t)gj[e];
@@ -157,13 +222,19 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
   p->max_source = max_src;
   p->max_in_degree = max_in;
   p->max_out_degree = max_out;
-  int rc = BSMS_OK;
-  if ((rc = upload(&p->rowptr, rowptr)) || (rc = upload(&p->src, src)) || (rc = upload(&p->dst, dst)) ||
-      (rc = upload(&p->perm, perm)) || (rc = upload(&p->t_rowptr, t_rowptr)) ||
-      (rc = upload(&p->t_dst, t_dst)) || (rc = upload(&p->t_eid, t_eid)) || (rc = upload(&p->t_pos, t_pos))) {
+  int rc = upload_block(&p->block, &p->block_cap, blk);
+  if (rc) {
     bsms_plan_destroy(p);
     return rc;
   }
+  p->rowptr = p->block;
+  p->t_rowptr = p->rowptr + nN;
+  p->src = p->t_rowptr + nN;
+  p->dst = p->src + nE;
+  p->perm = p->dst + nE;
+  p->t_dst = p->perm + nE;
+  p->t_eid = p->t_dst + nE;
+  p->t_pos = p->t_eid + nE;
   *out = p;
   return BSMS_OK;
 }
@@ -172,7 +243,9 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
   BSMS_REQUIRE(p != nullptr, BSMS_E_INVALID_ARG, "plan_set_pool: plan is null");
   BSMS_REQUIRE(Nk >= 0 && Nk <= p->N && (ids != nullptr || Nk == 0), BSMS_E_SHAPE,
                "plan_set_pool: bad Nk=%lld for N=%lld", (long long)Nk, (long long)p->N);
-  std::vector<int32_t> h_ids(Nk), h_inv(p->N, -1);
+  const size_t nK = idx_pad(size_t(Nk));
+  std::vector<int32_t> blk(nK + idx_pad(size_t(p->N)), -1);
+  int32_t *h_ids = blk.data(), *h_inv = h_ids + nK;
   for (int64_t k = 0; k < Nk; ++k) {
     BSMS_REQUIRE(ids[k] >= 0 && ids[k] < p->N, BSMS_E_INVALID_ARG, "plan_set_pool: id %lld out of range",
                  (long long)ids[k]);
@@ -180,21 +253,33 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
     h_ids[k] = (int32_t)ids[k];
     h_inv[ids[k]] = (int32_t)k;
   }
-  if (p->ids) (void)hipFree(p->ids);
-  if (p->inv) (void)hipFree(p->inv);
-  p->ids = p->inv = nullptr;
+  release_block(p->pool_block, p->pool_cap);
+  p->pool_block = p->ids = p->inv = nullptr;
+  p->Nk = 0;
   int rc;
-  if ((rc = upload(&p->ids, h_ids)) || (rc = upload(&p->inv, h_inv))) return rc;
+  if ((rc = upload_block(&p->pool_block, &p->pool_cap, blk))) return rc;
+  p->ids = p->pool_block;
+  p->inv = p->pool_block + nK;
   p->Nk = Nk;
   return BSMS_OK;
 }
 
 extern "C" int bsms_plan_destroy(bsms_plan_t* p) {
   if (!p) return BSMS_OK;
-  int32_t* bufs[] = {p->rowptr, p->src, p->dst, p->perm, p->t_rowptr, p->t_dst, p->t_eid, p->t_pos, p->ids, p->inv};
-  for (int32_t* b : bufs)
-    if (b) (void)hipFree(b);
+  release_block(p->block, p->block_cap);
+  release_block(p->pool_block, p->pool_cap);
   delete p;
+  return BSMS_OK;
+}
+
+extern "C" int bsms_plan_pool_trim(void) {
+  std::vector<PoolBlock> blocks;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    blocks.swap(g_pool);
+    g_pool_bytes = 0;
+  }
+  for (const PoolBlock& b : blocks) (void)hipFree(b.ptr);
   return BSMS_OK;
 }
 

@@ -6,6 +6,7 @@ is converted once into a destination-sorted CSR + source-sorted transpose held i
 import ctypes as C
 import hashlib
 import os
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -14,14 +15,28 @@ import torch
 from . import _abi
 
 
+_COUNT_LOCK = threading.Lock()
+
+
+def _host_copy(t):
+    """CPU int64 copy of an index tensor.  Tensors that came through `intern_index` carry their host original
+    (`_bsms_host`): reading a device tensor back would wait for everything queued on the stream -- with variable meshes
+    (new plans every batch) that is a pipeline drain per level and step."""
+    host = getattr(t, "_bsms_host", None)
+    if host is not None and host.shape == t.shape and host.dtype == torch.int64:
+        return host
+    return t.detach().to("cpu", torch.int64).contiguous()
+
+
 class LevelPlan:
     """One mesh level (optionally with the kept-node ids of the level for restrict/prolong)."""
 
     constructed = 0   # number of plans built so far (tests assert that a consistent mesh builds its plans ONCE)
 
     def __init__(self, g, num_nodes, ids=None, device=None):
-        LevelPlan.constructed += 1
-        g_cpu = g.detach().to("cpu", torch.int64).contiguous()
+        with _COUNT_LOCK:
+            LevelPlan.constructed += 1
+        g_cpu = _host_copy(g)
         if g_cpu.dim() != 2 or g_cpu.shape[0] != 2:
             raise ValueError(f"edge list must be [2, E], got {tuple(g_cpu.shape)}")
         self.device = torch.device(device if device is not None else g.device)
@@ -40,7 +55,7 @@ class LevelPlan:
             self.set_pool(ids)
 
     def set_pool(self, ids):
-        ids_cpu = np.ascontiguousarray(ids.detach().to("cpu", torch.int64).numpy())
+        ids_cpu = np.ascontiguousarray(_host_copy(ids).numpy())
         with torch.cuda.device(self.device):
             _abi.check(_abi.lib().bsms_plan_set_pool(self._h, ids_cpu.ctypes.data, int(ids_cpu.shape[0])), "bsms_plan_set_pool")
         self.Nk = int(ids_cpu.shape[0])
@@ -63,9 +78,44 @@ class LevelPlan:
         h, self._h = getattr(self, "_h", None), None
         if h:
             try:
+                _retire(h, getattr(self, "device", None))
+            except Exception:      # interpreter shutdown: module globals are already gone, the process frees the device
+                pass
+
+
+# Plans whose Python handle is gone but whose kernels may still be queued: the library recycles a destroyed plan's device
+# block without waiting (include/bsms_hip.h), so a plan is destroyed only after an event recorded on the device's current
+# stream at retirement has completed (the engine joins its side streams into the caller's stream before every return).
+_GRAVE = []
+
+
+def _reap():
+    keep = []
+    for ev, h in _GRAVE:
+        try:
+            done = ev is None or ev.query()
+        except Exception:
+            done = True
+        if done:
+            try:
                 _abi.lib().bsms_plan_destroy(h)
             except Exception:
                 pass
+        else:
+            keep.append((ev, h))
+    _GRAVE[:] = keep
+
+
+def _retire(h, device):
+    ev = None
+    try:
+        if device is not None and torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+    except Exception:      # interpreter shutdown
+        ev = None
+    _GRAVE.append((ev, h))
+    _reap()
 
 
 def _cache_capacity():
@@ -94,6 +144,8 @@ class _PlanCache:
         if hit is not None:
             self._d.move_to_end(key)
             return hit[0]
+        if _GRAVE:
+            _reap()
         plan = LevelPlan(g, num_nodes, ids)
         self._d[key] = (plan, g.untyped_storage(), ids.untyped_storage() if ids is not None else None)
         if len(self._d) > self.capacity:
@@ -110,6 +162,31 @@ _CACHE = _PlanCache()
 def plan_for(g, num_nodes, ids=None):
     """Cached LevelPlan for edge tensor `g` ([2,E] int64 on the GPU) of a level with `num_nodes`."""
     return _CACHE.get(g, num_nodes, ids)
+
+
+_BUILDERS = None
+
+
+def plans_for(specs):
+    """plan_for over a list of (g, num_nodes, ids): the plans that are not cached are built CONCURRENTLY (the host CSR
+    build of bsms_plan_create runs without the GIL; a variable-mesh batch needs L + 1 new plans every step, 2.3 ms
+    serially at cylinder size -- about the whole GPU step)."""
+    global _BUILDERS
+    keys = [(_key(g), int(n), _key(ids) if ids is not None else None) for g, n, ids in specs]
+    missing = [i for i, k in enumerate(keys) if k not in _CACHE._d]
+    if len(missing) >= 2:
+        if _BUILDERS is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _BUILDERS = ThreadPoolExecutor(max_workers=8, thread_name_prefix="bsms-plan")
+        if _GRAVE:
+            _reap()
+        built = list(_BUILDERS.map(lambda i: LevelPlan(*specs[i]), missing))
+        for i, plan in zip(missing, built):
+            g, _, ids = specs[i]
+            _CACHE._d[keys[i]] = (plan, g.untyped_storage(), ids.untyped_storage() if ids is not None else None)
+        while len(_CACHE._d) > _CACHE.capacity:
+            _CACHE._d.popitem(last=False)
+    return [_CACHE.get(g, n, ids) for g, n, ids in specs]
 
 
 def clear_plan_cache():
@@ -136,6 +213,15 @@ def _content_key(t):
     return (tuple(t.shape), str(t.dtype), digest)
 
 
+def _upload(t, device):
+    """Host -> device without waiting for the stream: a blocking `.to()` of pageable memory returns only after everything
+    queued before it has run (a pipeline drain per tensor when every batch brings new tensors).  Pinned staging comes
+    from PyTorch's caching host allocator, which keeps the block alive until the copy has executed."""
+    if not t.is_cuda and torch.device(device).type == "cuda":
+        return (t if t.is_pinned() else t.pin_memory()).to(device, non_blocking=True)
+    return t.to(device)
+
+
 def intern_index(t, device, shared_batch_axis=False):
     """Device copy of the CPU int64 index tensor `t`, shared between calls with equal content.
     shared_batch_axis: `t` is [B, ...] and the consumer reads t[0] only (consistent-mesh collate, models/model.py:190-192);
@@ -154,9 +240,10 @@ def intern_index(t, device, shared_batch_axis=False):
         return hit[0]
     host = src.contiguous().clone()
     if first is not None:
-        dev = host.to(device).unsqueeze(0).expand(t.shape[0], *first.shape)
+        dev = _upload(host, device).unsqueeze(0).expand(t.shape[0], *first.shape)
     else:
-        dev = host.to(device)
+        dev = _upload(host, device)
+        dev._bsms_host = host                  # LevelPlan builds its CSR from the host original (no device read-back)
     _INTERNED[key] = (dev, host)
     if len(_INTERNED) > _cache_capacity():
         _INTERNED.popitem(last=False)
@@ -172,7 +259,7 @@ class LevelData:
         self.edge_index, self.num_nodes, self.face, self.x, self.y, self.mask = edge_index, num_nodes, face, x, y, mask
 
     def to(self, device, intern=False):
-        mv = lambda t: None if t is None else t.to(device)
+        mv = lambda t: None if t is None else _upload(t, device)
         mi = (lambda t: None if t is None else intern_index(t, device)) if intern else mv
         return LevelData(mi(self.edge_index), self.num_nodes, mi(self.face), mv(self.x), mv(self.y), mv(self.mask))
 

@@ -21,7 +21,7 @@ from torch import nn
 import os
 
 from . import _abi
-from .graph import LevelPlan, plan_for
+from .graph import LevelPlan, plan_for, plans_for
 
 __all__ = ["MLP", "GMP", "WeightedEdgeConv", "Unpool", "BSGMP", "InferenceSession", "scatter_sum", "degree"]
 
@@ -638,11 +638,10 @@ class BSGMP(nn.Module):
 
     def prepare(self, m_ids, m_gs, n0, device):
         """(plans of levels 0..L-1 with their pools, cached edge weights, plan of the bottom level) of a hierarchy."""
-        plans, n_l = [], n0
-        for i in range(self.unet_depth):                     # plans first: they fix the level sizes
-            plans.append(plan_for(m_gs[i], n_l, m_ids[i]))
-            n_l = plans[-1].Nk
-        return plans, self._edge_weights(plans, m_ids, device), plan_for(m_gs[self.unet_depth], n_l)
+        sizes = [int(n0)] + [int(ids.shape[0]) for ids in m_ids[:self.unet_depth]]      # N_l = number of kept ids of level l - 1
+        specs = [(m_gs[i], sizes[i], m_ids[i] if i < self.unet_depth else None) for i in range(self.unet_depth + 1)]
+        *plans, bottom = plans_for(specs)                    # new meshes: all levels are built concurrently
+        return plans, self._edge_weights(plans, m_ids, device), bottom
 
     def block_params(self):
         """Parameters in the order of the bsms_bsgmp_* entries: down 0..L-1, bottom, up 0..L-1; node MLP then edge MLP."""

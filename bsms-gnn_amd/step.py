@@ -25,6 +25,31 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+class _Arena:
+    """Grow-only device buffers by name.  With variable meshes (the reference's cylinder_flow path) every batch has its
+    own node / edge counts: buffers sized exactly would be released and re-allocated every step -- hundreds of MB through
+    hipMalloc, 30-70 ms per step against a 2.5 ms step (profiles/fresh_mesh.py).  A buffer is re-allocated only when
+    a batch needs more than its capacity, then with 25 % headroom."""
+
+    def __init__(self):
+        self._t = {}
+
+    def bytes(self, name, nbytes, dev):
+        nbytes = max(int(nbytes), 1)
+        t = self._t.get(name)
+        if t is None or t.numel() < nbytes or t.device != dev:
+            cap = nbytes if t is None else nbytes + nbytes // 4
+            self._t[name] = None                     # release the old block before asking for the larger one
+            t = self._t[name] = torch.empty((cap + 255) // 256 * 256, device=dev, dtype=torch.uint8)
+        return t[:nbytes]
+
+    def f32(self, name, dev, *shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return self.bytes(name, 4 * max(n, 1), dev)[:4 * n].view(torch.float32).view(*shape)
+
+
 class FusedStep:
     def __init__(self, model, grads, group=None, use_graph=False):
         from .model import BSMS_Simulator
@@ -34,6 +59,7 @@ class FusedStep:
             raise ValueError("FusedStep uses the one-call U-Net (BSGMP.per_block must be False)")
         self.model, self.grads, self.group, self.use_graph = model, grads, group, use_graph
         self._shape_key, self._graphs, self._ptr_guard = None, None, None
+        self._arena = _Arena()
         for p in grads.params:                      # .grad aliases the flat buffer once and for all
             off, n = grads._slot[p]
             p.grad = grads.flat[off:off + n].view_as(p)
@@ -102,18 +128,20 @@ class FusedStep:
             return self._buf
         R, depth = B * N, len(plans) - 1
         pl, keep = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in plans])
-        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        u8 = lambda n: torch.empty(max(int(n), 1), device=dev, dtype=torch.uint8)
+        ar = self._arena                              # views of grow-only buffers: a batch of another size re-uses the memory
+        f = lambda name, *s: ar.f32(name, dev, *s)
+        u8 = lambda name, n: ar.bytes(name, n, dev)
         b = dict(R=R, pl=pl, pl_keep=keep, plans=plans, depth=depth,
-                 norm_in=f(R, C + 1), pos=f(R, p), h0=f(R, D), h1=f(R, D), norm_pred=f(R, C), pred=f(B, N, C),
-                 sums=f(2), loss=f(1), g_np=f(R, C), gh1=f(R, D), gh0=f(R, D),
-                 s_enc=u8(L.bsms_mlp_saved_bytes(R, C + 1, D, D, H)), s_dec=u8(L.bsms_mlp_saved_bytes(R, D, D, C, H)),
-                 s_proc=u8(L.bsms_bsgmp_saved_bytes_p(pl, depth, B, D, p, H, PRECISIONS[m.process.precision])),
+                 norm_in=f("norm_in", R, C + 1), pos=f("pos", R, p), h0=f("h0", R, D), h1=f("h1", R, D),
+                 norm_pred=f("norm_pred", R, C), pred=f("pred", B, N, C),
+                 sums=f("sums", 2), loss=f("loss", 1), g_np=f("g_np", R, C), gh1=f("gh1", R, D), gh0=f("gh0", R, D),
+                 s_enc=u8("s_enc", L.bsms_mlp_saved_bytes(R, C + 1, D, D, H)), s_dec=u8("s_dec", L.bsms_mlp_saved_bytes(R, D, D, C, H)),
+                 s_proc=u8("s_proc", L.bsms_bsgmp_saved_bytes_p(pl, depth, B, D, p, H, PRECISIONS[m.process.precision])),
                  prec=m.process.precision,
-                 work=u8(max(L.bsms_mlp_work_bytes(R, C + 1, D, D, H), L.bsms_mlp_work_bytes(R, D, D, C, H),
-                             L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, H), L.bsms_sim_work_bytes(R))),
-                 work_enc=u8(L.bsms_mlp_work_bytes(R, C + 1, D, D, H)),   # the encoder's backward overlaps the U-Net's last weight gradients
-                 work_dec=u8(L.bsms_mlp_work_bytes(R, D, D, C, H)),       # the decoder's weight gradients run under the U-Net's first block
+                 work=u8("work", max(L.bsms_mlp_work_bytes(R, C + 1, D, D, H), L.bsms_mlp_work_bytes(R, D, D, C, H),
+                                     L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, H), L.bsms_sim_work_bytes(R))),
+                 work_enc=u8("work_enc", L.bsms_mlp_work_bytes(R, C + 1, D, D, H)),   # the encoder's backward overlaps the U-Net's last weight gradients
+                 work_dec=u8("work_dec", L.bsms_mlp_work_bytes(R, D, D, C, H)),       # the decoder's weight gradients run under the U-Net's first block
                  in_static=None)
         self._shape_key, self._buf, self._graphs = key, b, None
         return b

@@ -90,14 +90,14 @@ class Trainer:
         """trainer/trainer.py:143 semantics (nested lists -> device), except that INDEX tensors (edge lists, kept ids)
         are interned by content (graph.intern_index): a batch of the same mesh maps to the same device tensors every
         step, so the per-mesh plans (CSR layouts, edge weights) are built once, not once per step."""
-        from .graph import LevelData, intern_index
+        from .graph import LevelData, intern_index, _upload
         if isinstance(data, (list, tuple)):
             return [self.move_to_device(d) for d in data]
         if isinstance(data, LevelData):
             return data.to(self.device, intern=True)
         if data.dtype == torch.int64 and not data.is_cuda:
             return intern_index(data, self.device, shared_batch_axis=bool(self.model_cfg.consistent_mesh))
-        return data.to(self.device)
+        return _upload(data, self.device)
 
     def _warming_up(self):
         return self.train_step < self.model_cfg.accumulation_steps

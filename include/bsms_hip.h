@@ -72,10 +72,15 @@ const char* bsms_last_error(void);
  * gathers and the up-pass.  `coo_host` is a HOST pointer to int64 [2,E].  Indices must be
  * < 2^31.  bsms_plan_set_pool attaches the kept-node ids of the level (m_ids[l],
  * graph_wrappers/bsms_graph_wrapper.py:97-98; HOST int64 [Nk], ascending) for the fused
- * restrict / prolong kernels. */
+ * restrict / prolong kernels.
+ * The index buffers of a plan are ONE device block, uploaded on a private stream (creating a plan does not wait for work
+ * queued on the caller's streams).  bsms_plan_destroy / a second bsms_plan_set_pool hand the block to an internal pool
+ * instead of hipFree (which would wait for the whole device): the caller guarantees that nothing using the plan is
+ * still in flight, as for any buffer it owns.  bsms_plan_pool_trim releases the pooled blocks (waits for the device). */
 int bsms_plan_create(const int64_t* coo_host, int64_t E, int64_t N, bsms_plan_t** out);
 int bsms_plan_set_pool(bsms_plan_t* plan, const int64_t* ids_host, int64_t Nk);
 int bsms_plan_destroy(bsms_plan_t* plan);
+int bsms_plan_pool_trim(void);
 int64_t bsms_plan_num_nodes(const bsms_plan_t* plan);
 int64_t bsms_plan_num_edges(const bsms_plan_t* plan);
 int64_t bsms_plan_num_pooled(const bsms_plan_t* plan);  /* Nk, 0 if no pool attached */
