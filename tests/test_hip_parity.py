@@ -55,6 +55,48 @@ def test_plan_matches_stable_sort(eng):
         eng.LevelPlan(torch.tensor([[0, 5], [1, 2]]).cuda(), 3)      # out-of-range endpoint
 
 
+def _plan_arrays_ok(plan, g, n):
+    rp, src, perm, trp = plan.export()
+    order = np.argsort(g[1].numpy(), kind="stable")
+    return (np.array_equal(perm, order.astype(np.int32)) and np.array_equal(src, g[0].numpy()[order].astype(np.int32))
+            and np.array_equal(rp, np.concatenate([[0], np.cumsum(np.bincount(g[1].numpy(), minlength=n))]).astype(np.int32))
+            and np.array_equal(trp, np.concatenate([[0], np.cumsum(np.bincount(g[0].numpy(), minlength=n))]).astype(np.int32)))
+
+
+def test_plans_of_new_meshes_recycled_blocks_and_concurrent_builds(eng):
+    """Variable meshes bring new plans every batch: device blocks of destroyed plans are recycled (no hipFree), the
+    levels of a batch are built concurrently, interned index tensors hand their host original to the builder.  Every
+    plan must still be the stable sort of ITS edge list, and the kernels must read the recycled block's new content."""
+    import gc
+    from bsms_gnn_amd import graph
+    eng.clear_plan_cache()
+    rng = np.random.default_rng(3)
+    for rnd in range(6):                                   # sizes wander by +-20 %: recycled blocks of other capacities
+        sizes = [(int(97 * f), int(1000 * f)) for f in rng.uniform(0.8, 1.2, 5)]
+        gs = [random_graph(n, e, 100 * rnd + k, hub=3) for k, (n, e) in enumerate(sizes)]
+        ids = [torch.arange(0, n, 2) for n, _ in sizes]
+        dev_g = [graph.intern_index(g, "cuda") for g in gs]
+        dev_i = [graph.intern_index(i, "cuda") for i in ids]
+        assert all(getattr(t, "_bsms_host", None) is not None for t in dev_g + dev_i)
+        before = eng.LevelPlan.constructed
+        plans = graph.plans_for([(g, n, i) for g, (n, _), i in zip(dev_g, sizes, dev_i)])
+        assert eng.LevelPlan.constructed == before + 5
+        assert graph.plans_for([(g, n, i) for g, (n, _), i in zip(dev_g, sizes, dev_i)]) == plans   # cached now
+        for plan, g, (n, e), i in zip(plans, gs, sizes, ids):
+            assert _plan_arrays_ok(plan, g, n) and plan.Nk == i.numel()
+            src, out = dev(torch.randn(2, e, 8)), torch.empty(2, n, 8, device="cuda")
+            eng._abi.check(eng._abi.lib().bsms_segment_sum_fwd(plan.handle, src.data_ptr(), 2, 8, 0, out.data_ptr(),
+                                                               torch.cuda.current_stream().cuda_stream), "segment_sum")
+            assert torch.equal(out.cpu(), ro.scatter_sum(src.cpu(), g[1], -2, n))       # the kernels read the recycled block's new content
+        del plans, plan
+        eng.clear_plan_cache()
+        gc.collect()
+        torch.cuda.synchronize()
+        graph._reap()
+        assert not graph._GRAVE                              # retired after their event: blocks are back in the pool
+    assert eng._abi.lib().bsms_plan_pool_trim() == 0
+
+
 # ------------------------------------------------------------------------------------ A1 segment sum
 @pytest.mark.parametrize("B,D", [(1, 1), (2, 3), (3, 8), (2, 32), (2, 128), (1, 256), (2, 36)])
 def test_segment_sum_bit_exact(eng, B, D):

@@ -187,6 +187,41 @@ def test_fused_step_equals_autograd_step(eng, graphs):
     assert l2 == ref2 and l2 != l1
 
 
+def test_fused_step_over_batches_of_changing_size(eng, graphs):
+    """Variable meshes: every batch has its own node / edge counts.  The step's buffers are grow-only views (step._Arena);
+    a step on a batch must not depend on which batches came before it (smaller, larger, the same again)."""
+    cfg = ro.make_cfg(2, 32, 3, 2, 2)
+    torch.manual_seed(11)
+    sim = eng.BSMS_Simulator(cfg).cuda()
+
+    def sample(nm, seed):
+        es, ids = graphs.levels(nm)
+        n = graphs.np(f"{nm}/pos").shape[0]
+        gen = torch.Generator().manual_seed(seed)
+        pos = torch.tensor(graphs.np(f"{nm}/pos")[:, :2], dtype=torch.float32)
+        state = torch.randn(n, 2, generator=gen)
+        x, y = torch.cat([state, pos, torch.zeros(n, 1)], -1), state + 0.1 * torch.randn(n, 2, generator=gen)
+        sizes = [n] + [i.numel() for i in ids[:2]]
+        return [eng.LevelData(es[l], sizes[l], face=ids[l] if l < 2 else None, x=x if l == 0 else None,
+                              y=y if l == 0 else None, mask=torch.ones(n, 1) if l == 0 else None) for l in range(3)]
+
+    small, big = sample("del64", 0), sample("del300", 1)
+    batches = [eng.collate_variable_meshes(b) for b in ([small], [big, small], [big], [small, big, big], [small])]
+    to_dev = lambda b: [d.to("cuda", intern=True) for d in b]
+    sim(to_dev(batches[1]), False, True)                                   # normaliser statistics
+    want = []
+    for b in batches:                                                      # reference: a fresh step object per batch
+        grads = eng.GradBuckets(list(sim.parameters()))
+        want.append((float(eng.FusedStep(sim, grads)(to_dev(b), False)), grads.flat.clone()))
+    grads = eng.GradBuckets(list(sim.parameters()))
+    step = eng.FusedStep(sim, grads)
+    for b, (loss, flat) in zip(batches, want):
+        assert float(step(to_dev(b), False)) == loss and torch.equal(grads.flat, flat)
+    caps = {k: t.numel() for k, t in step._arena._t.items()}
+    step(to_dev(batches[0]), False)                                        # a small batch after the largest: nothing is re-allocated
+    assert caps == {k: t.numel() for k, t in step._arena._t.items()}
+
+
 def test_data_parallel_uses_the_fused_step(eng, graphs):
     """DataParallel.step_loss_backward == the autograd step (BSMS_FUSED_STEP=0 path), and the Trainer loop on top of it is
     covered by test_trainer_iterations_follow_cpu_reference_loop."""
