@@ -1626,7 +1626,8 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
   else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
   const dim3 threads((cw + a.nload) * 64);
-  const size_t lds = Ring<NB>::lds_bytes(a.nring);   // (the bf16 precision's chunks are smaller: the same allocation covers them)
+  // the bf16 precision's chunks are one plane: its ring may be deeper than the fp32 one at the same D, size it as what it is
+  const size_t lds = a.bf16 ? Ring<NB, 1>::lds_bytes(a.nring) : Ring<NB>::lds_bytes(a.nring);
   bool launched = false;
   if constexpr (NB == 8 && IN == IN_EDGE) {   // the only instantiation with stamps
     if (a.timing) {
@@ -1693,7 +1694,7 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
   else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
   const dim3 threads((cw + a.nload) * 64);
-  const size_t lds = Ring<NB>::lds_bytes(a.nring);
+  const size_t lds = a.bf16 ? Ring<NB, 1>::lds_bytes(a.nring) : Ring<NB>::lds_bytes(a.nring);   // see launch_fwd_t
   if constexpr ((NB == 8 || NB == 16) && GIN == G_EDGE_LN && FIRST == F_NONE) {
     int rc = BSMS_OK;
     if (launch_edge_bwd<NB>(a, s, rc)) return rc;

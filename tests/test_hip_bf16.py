@@ -62,19 +62,19 @@ def emulate(net):
 def test_bf16_forward_matches_the_documented_arithmetic(eng, graphs):
     es, ids = graphs.levels("del300")
     torch.manual_seed(0)
-    for depth in (0, 2):
-        ref = ro.BSGMP(depth, 128, 3, 2)
-        mine = eng.BSGMP(depth, 128, 3, 2)
+    for depth, D in ((0, 128), (2, 128), (2, 256)):     # D = 256 on a small mesh: single-round launches with the deep one-plane ring
+        ref = ro.BSGMP(depth, D, 3, 2)
+        mine = eng.BSGMP(depth, D, 3, 2)
         mine.load_state_dict(ref.state_dict())
         mine = mine.cuda()
         mine.precision = "bf16"
-        h, pos = torch.randn(2, 300, 128), graphs.t("del300/pos").float().unsqueeze(0).repeat(2, 1, 1)
+        h, pos = torch.randn(2, 300, D), graphs.t("del300/pos").float().unsqueeze(0).repeat(2, 1, 1)
         with torch.no_grad():
             want32 = ref(h, ids[:depth], es[: depth + 1], pos)
             want = emulate(ref)(h, ids[:depth], es[: depth + 1], pos)
             got = mine(h.cuda(), [i.cuda() for i in ids[:depth]], [e.cuda() for e in es[: depth + 1]], pos.cuda()).cpu()
-        assert rel_err(got, want) < 3e-3, depth
-        assert 1e-4 < rel_err(got, want32) < 3e-2, depth          # it really is a different precision, and a usable one
+        assert rel_err(got, want) < 3e-3, (depth, D)
+        assert 1e-4 < rel_err(got, want32) < 3e-2, (depth, D)          # it really is a different precision, and a usable one
         # training forward (activations saved as bf16) == inference forward, bit for bit
         hh = h.cuda().requires_grad_(True)
         y = mine(hh, [i.cuda() for i in ids[:depth]], [e.cuda() for e in es[: depth + 1]], pos.cuda())
