@@ -10,6 +10,6 @@ from .dp import DataParallel, GradBuckets, global_masked_rmse  # noqa: F401
 from .hierarchy import BistrideMultiLayerGraph, to_flat_edge  # noqa: F401
 from .rollout import rollout_batch, rollout_one_traj, rollout_rmse  # noqa: F401
 from .step import FusedStep  # noqa: F401
-from .trainer import FusedAdamW, Trainer, WarmupCosineDecay  # noqa: F401
+from .trainer import DevicePrefetcher, FusedAdamW, Trainer, WarmupCosineDecay  # noqa: F401
 
 __version__ = "0.1.0"

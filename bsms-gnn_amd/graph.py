@@ -16,6 +16,7 @@ from . import _abi
 
 
 _COUNT_LOCK = threading.Lock()
+_LOCK = threading.RLock()      # plan cache + interned-index table: a prefetch thread (trainer.DevicePrefetcher) fills them while the training thread reads
 
 
 def _host_copy(t):
@@ -140,17 +141,18 @@ class _PlanCache:
 
     def get(self, g, num_nodes, ids=None):
         key = (_key(g), int(num_nodes), _key(ids) if ids is not None else None)
-        hit = self._d.get(key)
-        if hit is not None:
-            self._d.move_to_end(key)
-            return hit[0]
-        if _GRAVE:
-            _reap()
-        plan = LevelPlan(g, num_nodes, ids)
-        self._d[key] = (plan, g.untyped_storage(), ids.untyped_storage() if ids is not None else None)
-        if len(self._d) > self.capacity:
-            self._d.popitem(last=False)
-        return plan
+        with _LOCK:
+            hit = self._d.get(key)
+            if hit is not None:
+                self._d.move_to_end(key)
+                return hit[0]
+            if _GRAVE:
+                _reap()
+            plan = LevelPlan(g, num_nodes, ids)
+            self._d[key] = (plan, g.untyped_storage(), ids.untyped_storage() if ids is not None else None)
+            if len(self._d) > self.capacity:
+                self._d.popitem(last=False)
+            return plan
 
     def clear(self):
         self._d.clear()
@@ -173,20 +175,21 @@ def plans_for(specs):
     serially at cylinder size -- about the whole GPU step)."""
     global _BUILDERS
     keys = [(_key(g), int(n), _key(ids) if ids is not None else None) for g, n, ids in specs]
-    missing = [i for i, k in enumerate(keys) if k not in _CACHE._d]
-    if len(missing) >= 2:
-        if _BUILDERS is None:
-            from concurrent.futures import ThreadPoolExecutor
-            _BUILDERS = ThreadPoolExecutor(max_workers=8, thread_name_prefix="bsms-plan")
-        if _GRAVE:
-            _reap()
-        built = list(_BUILDERS.map(lambda i: LevelPlan(*specs[i]), missing))
-        for i, plan in zip(missing, built):
-            g, _, ids = specs[i]
-            _CACHE._d[keys[i]] = (plan, g.untyped_storage(), ids.untyped_storage() if ids is not None else None)
-        while len(_CACHE._d) > _CACHE.capacity:
-            _CACHE._d.popitem(last=False)
-    return [_CACHE.get(g, n, ids) for g, n, ids in specs]
+    with _LOCK:
+        missing = [i for i, k in enumerate(keys) if k not in _CACHE._d]
+        if len(missing) >= 2:
+            if _BUILDERS is None:
+                from concurrent.futures import ThreadPoolExecutor
+                _BUILDERS = ThreadPoolExecutor(max_workers=8, thread_name_prefix="bsms-plan")
+            if _GRAVE:
+                _reap()
+            built = list(_BUILDERS.map(lambda i: LevelPlan(*specs[i]), missing))
+            for i, plan in zip(missing, built):
+                g, _, ids = specs[i]
+                _CACHE._d[keys[i]] = (plan, g.untyped_storage(), ids.untyped_storage() if ids is not None else None)
+            while len(_CACHE._d) > _CACHE.capacity:
+                _CACHE._d.popitem(last=False)
+        return [_CACHE.get(g, n, ids) for g, n, ids in specs]
 
 
 def clear_plan_cache():
@@ -240,6 +243,11 @@ def _upload(t, device):
 
 
 def intern_index(t, device, shared_batch_axis=False):
+    with _LOCK:
+        return _intern_index(t, device, shared_batch_axis)
+
+
+def _intern_index(t, device, shared_batch_axis=False):
     """Device copy of the CPU int64 index tensor `t`, shared between calls with equal content.
     shared_batch_axis: `t` is [B, ...] and the consumer reads t[0] only (consistent-mesh collate, models/model.py:190-192);
     when all B slices are equal only ONE slice is uploaded and the result is an expanded (stride-0) view, so the cache

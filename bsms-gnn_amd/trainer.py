@@ -70,6 +70,59 @@ class FusedAdamW:
         self.step_count = int(sd["step"])
 
 
+class DevicePrefetcher:
+    """`for batch in DevicePrefetcher(loader, trainer): trainer.iter(batch)` -- a background thread takes the host batches of
+    `loader` one ahead of the training thread: uploads (pinned, on the copy stream), interning of the index tensors, and
+    -- what matters for variable meshes, where every batch is a new block-diagonal graph -- the plans (host CSR builds)
+    and the edge-weight chain of the batch.  The training thread then only enqueues the step.  The reference has no
+    counterpart (its DataLoader hands CPU batches to `move_to_device`, trainer/trainer.py:143); results are identical to
+    feeding `trainer.iter` directly."""
+
+    _END = object()
+
+    def __init__(self, loader, trainer, depth=2):
+        self.loader, self.trainer, self.depth = loader, trainer, max(int(depth), 1)
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+
+        def put(item):                 # bounded put that gives up when the consumer has gone away
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                torch.cuda.set_device(self.trainer.device)
+                for data in self.loader:
+                    if not put(self.trainer.prefetch(data)):
+                        return
+                put(self._END)
+            except BaseException as e:     # surfaces in the training thread
+                put(e)
+
+        th = threading.Thread(target=work, name="bsms-prefetch", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is self._END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            th.join(timeout=5.0)
+
+
 class Trainer:
     """src/trainer/trainer.py:9-229.  `model_cfg` needs consistent_mesh, accumulation_steps; `opt_cfg` needs
     peak_lr, weight_decay, warmup_steps, decay_steps, gnorm_clip (configs/opt/default.yaml)."""
@@ -98,6 +151,20 @@ class Trainer:
         if data.dtype == torch.int64 and not data.is_cuda:
             return intern_index(data, self.device, shared_batch_axis=bool(self.model_cfg.consistent_mesh))
         return _upload(data, self.device)
+
+    def prefetch(self, data):
+        """move_to_device + everything mesh-dependent a step of this batch will look up (plans, edge weights): what
+        DevicePrefetcher runs one batch ahead.  Returns the device batch; `iter` accepts it as it accepts a host batch."""
+        data = self.move_to_device(data)
+        if self.model_cfg.consistent_mesh:
+            node_in, m_gs, m_ids = data[0], [g[0] for g in data[3]], [i[0] for i in data[4]]
+            n0 = node_in.shape[1]
+        else:
+            m_gs = [d.edge_index for d in data]
+            m_ids = [data[i].face for i in range(len(m_gs) - 1)]
+            n0 = data[0].x.shape[0]
+        self.model.process.prepare(m_ids, m_gs, n0, self.device)
+        return data
 
     def _warming_up(self):
         return self.train_step < self.model_cfg.accumulation_steps

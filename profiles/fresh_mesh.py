@@ -70,3 +70,19 @@ if os.environ.get("FRESH_PROFILE"):
     dp.step_loss_backward(d, False); torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+
+# ---- the same stream of fresh batches through Trainer.iter, alone and behind the prefetch thread
+from types import SimpleNamespace
+cfg = make_cfg(w); cfg.consistent_mesh = False
+torch.manual_seed(0)
+tr = eng.Trainer(eng.BSMS_Simulator(cfg).cuda(), cfg, SimpleNamespace(peak_lr=1e-4, weight_decay=1e-4, warmup_steps=10, decay_steps=10000, gnorm_clip=1.0))
+tr.model(to_dev(batch()), False, True)
+for name, wrap in (("Trainer.iter", lambda it: it), ("Trainer.iter behind DevicePrefetcher", lambda it: eng.DevicePrefetcher(it, tr))):
+    for b in wrap([batch() for _ in range(20)]):
+        tr.iter(b)
+    batches = [batch() for _ in range(N)]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for b in wrap(batches):
+        tr.iter(b)
+    torch.cuda.synchronize()
+    print(f"fresh batches, {name}: {(time.perf_counter() - t0) / N * 1e3:7.2f} ms/step")

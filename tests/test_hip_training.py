@@ -138,6 +138,15 @@ def test_datapipe_to_trainer_end_to_end(eng, consistent):
     if consistent:
         assert built[-1] == built[1], "plans of a consistent mesh are built once (warm-up builds none, step 1 builds them)"
     assert float(tr.optimizer.grad_norm) > 0
+    # the same stream of batches behind the prefetch thread (uploads, plans and edge weights one batch ahead): same numbers
+    ds2 = dpipe.TrajectoryDataset(dcfg, trajs, dataset="airfoil" if consistent else "cylinder_flow", mode="train", seed=0)
+    torch.manual_seed(0)
+    tr2 = eng.Trainer(eng.BSMS_Simulator(model_cfg), model_cfg, opt_cfg)
+    losses2 = [float(out) for out in (tr2.iter(b) for b in eng.DevicePrefetcher(dpipe.make_loader(ds2, 2), tr2)) if out is not None]
+    assert losses2 == losses
+    with pytest.raises(ZeroDivisionError):                # an error in the loader surfaces in the training thread
+        for _ in eng.DevicePrefetcher((1 // 0 for _ in range(1)), tr2):
+            pass
 
 
 def _sim_batch(eng, graphs, B=2):
