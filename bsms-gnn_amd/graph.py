@@ -49,6 +49,7 @@ class LevelPlan:
         with torch.cuda.device(self.device):
             _abi.check(_abi.lib().bsms_plan_create(coo.ctypes.data, self.E, self.N, C.byref(handle)), "bsms_plan_create")
         self._h = handle
+        self._used = set()
         self.Nk = 0
         self.max_source = int(_abi.lib().bsms_plan_max_source(self._h))
         self.min_out_degree = int(_abi.lib().bsms_plan_min_out_degree(self._h))
@@ -63,6 +64,12 @@ class LevelPlan:
 
     @property
     def handle(self):
+        """The `bsms_plan_t*` for a C-ABI call.  Every access notes the current stream: a retired plan is destroyed only
+        after the work queued so far on every stream that used it has completed (_retire)."""
+        try:
+            self._used.add(torch.cuda.current_stream(self.device))
+        except Exception:
+            pass
         return self._h
 
     def export(self):
@@ -79,14 +86,15 @@ class LevelPlan:
         h, self._h = getattr(self, "_h", None), None
         if h:
             try:
-                _retire(h, getattr(self, "device", None))
+                _retire(h, getattr(self, "device", None), getattr(self, "_used", ()))
             except Exception:      # interpreter shutdown: module globals are already gone, the process frees the device
                 pass
 
 
 # Plans whose Python handle is gone but whose kernels may still be queued: the library recycles a destroyed plan's device
-# block without waiting (include/bsms_hip.h), so a plan is destroyed only after an event recorded on the device's current
-# stream at retirement has completed (the engine joins its side streams into the caller's stream before every return).
+# block without waiting (include/bsms_hip.h), so a plan is destroyed only after events recorded at retirement on the
+# current stream and on every stream the plan was used on have completed (the engine joins its side streams into the
+# caller's stream before every return).
 _GRAVE = []
 
 
@@ -94,7 +102,7 @@ def _reap():
     keep = []
     for ev, h in _GRAVE:
         try:
-            done = ev is None or ev.query()
+            done = all(e.query() for e in ev)
         except Exception:
             done = True
         if done:
@@ -107,15 +115,17 @@ def _reap():
     _GRAVE[:] = keep
 
 
-def _retire(h, device):
-    ev = None
+def _retire(h, device, used=()):
+    evs = []
     try:
         if device is not None and torch.cuda.is_available():
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(device))
+            for st in {torch.cuda.current_stream(device), *used}:
+                e = torch.cuda.Event()
+                e.record(st)
+                evs.append(e)
     except Exception:      # interpreter shutdown
-        ev = None
-    _GRAVE.append((ev, h))
+        evs = []
+    _GRAVE.append((evs, h))
     _reap()
 
 
