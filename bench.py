@@ -279,7 +279,7 @@ def roofline_objects(wl, batch, dtype="f32"):
     gbs = lambda t_ms: algo / (t_ms * 1e-3) / 1e9
     if bf:
         traffic, in_step = None, None   # the PMC passes and the in-step profile were taken for the fp32 kernel
-    roof = {"kernel": ("k_rowsum_bf16in<32,false> (L0 edge aggregation of the bf16 precision, bsms_segment_sum_bf16)" if bf else
+    roof = {"kernel": ("k_rowsum_bf16in (eight features per lane; L0 edge aggregation of the bf16 precision, bsms_segment_sum_bf16)" if bf else
                        "k_rowsum_v4<32,false,false,false> (L0 edge aggregation, bsms_segment_sum_fwd plan order)"),
             "bound": "hbm", "achieved": gbs(ms), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(ms) / HBM_PEAK_GBS,
             "traffic": traffic, "algorithmic_bytes": algo, "avg_us": ms * 1e3,

@@ -132,10 +132,46 @@ __global__ __launch_bounds__(256) void k_rowsum_v4(RowSumArgs a) {
   }
 }
 
-// the edge aggregation of the bf16 precision: messages stored as bf16, sums and output fp32
+// the edge aggregation of the bf16 precision: messages stored as bf16, sums and output fp32.
+// A lane owns EIGHT features (one 16-byte load per edge row, as in the fp32 kernel) and LPR = D / 8 lanes share an output
+// row: with four features per lane (8-byte loads) a wave had half the bytes in flight and the launch ran at 0.48 of the HBM
+// peak against 0.64 for the fp32 kernel on twice the bytes.  Every feature still sums its rows in slot order.
+template <int U>
+__device__ __forceinline__ void rowsum_batch_bf8(const unsigned short* x, int64_t xcol, int q, int D, float (&acc)[8]) {
+  uint4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const uint4*>(x + xcol + int64_t(q + u) * D);
+  __builtin_amdgcn_sched_barrier(0);   // all U row loads are in flight before the first add
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[2 * k] += __uint_as_float(w[k] << 16);
+      acc[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u);
+    }
+  }
+}
 template <int LPR, bool DEEP>
-__global__ __launch_bounds__(256) void k_rowsum_bf16in(RowSumArgs a) {
-  rowsum_body<LPR, false, false, DEEP, false, false, true>(a);
+__global__ __launch_bounds__(256) void k_rowsum_bf16in(RowSumArgs a) {   // D == 8 * LPR, plan order, no weights / maps / addend
+  const int64_t worker = (int64_t(blockIdx.x) * 256 + threadIdx.x) / LPR;
+  const int lane = threadIdx.x % LPR;
+  if (worker >= int64_t(a.B) * a.n_out) return;
+  const int b = int(worker / a.n_out), r = int(worker % a.n_out);
+  const int q0 = a.rowptr[r], q1 = a.rowptr[r + 1];
+  const unsigned short* x = reinterpret_cast<const unsigned short*>(a.x);
+  const int64_t xcol = b * a.x_bstride + lane * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int q = q0;
+  if (DEEP)
+    for (; q + 16 <= q1; q += 16) rowsum_batch_bf8<16>(x, xcol, q, a.D, acc);
+  for (; q + 8 <= q1; q += 8) rowsum_batch_bf8<8>(x, xcol, q, a.D, acc);
+#define BSMS_TAIL(K) case K: rowsum_batch_bf8<K>(x, xcol, q, a.D, acc); break
+  switch (q1 - q) { BSMS_TAIL(7); BSMS_TAIL(6); BSMS_TAIL(5); BSMS_TAIL(4); BSMS_TAIL(3); BSMS_TAIL(2); BSMS_TAIL(1); default: break; }
+#undef BSMS_TAIL
+  float4* ob = reinterpret_cast<float4*>(a.out + b * a.out_bstride + int64_t(r) * a.D + lane * 8);
+  ob[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  ob[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
 // two unweighted, unmapped sums of the SAME shape in one launch (blockIdx.y picks the job): the scatters of the first
@@ -403,15 +439,15 @@ int rowsum_plan_order_bf16(const bsms_plan* p, const float* x_bf16, int64_t B, i
   a.n_out = (int32_t)p->N; a.B = (int32_t)B; a.D = (int32_t)D;
   const int64_t workers = B * p->N;
   if (workers == 0) return BSMS_OK;
-  const int lpr = int(D / 4);
+  const int lpr = int(D / 8);   // eight features per lane
   const dim3 grid((unsigned)ceil_div(workers * lpr, 256));
-  const bool deep = workers * lpr < kDeepBelowThreads;
+  const bool deep = workers * (D / 4) < kDeepBelowThreads;   // the same levels as the fp32 kernel
   if (D == 128) {
+    if (deep) hipLaunchKernelGGL((k_rowsum_bf16in<16, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_rowsum_bf16in<16, false>), grid, dim3(256), 0, s, a);
+  } else {
     if (deep) hipLaunchKernelGGL((k_rowsum_bf16in<32, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_rowsum_bf16in<32, false>), grid, dim3(256), 0, s, a);
-  } else {
-    if (deep) hipLaunchKernelGGL((k_rowsum_bf16in<64, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_rowsum_bf16in<64, false>), grid, dim3(256), 0, s, a);
   }
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
