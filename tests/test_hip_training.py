@@ -292,7 +292,8 @@ def test_inference_session_sees_raw_pointer_updates(eng, graphs):
     sess = InferenceSession(static_pos=True)
     with torch.no_grad():
         a = tr.model._infer(ids, gs, node_in, mask, session=sess).clone()
-        tr.iter(data); tr.iter(data)                                      # lr > 0 from the second optimizer step on
+    tr.iter(data); tr.iter(data)                                          # lr > 0 from the second optimizer step on
+    with torch.no_grad():
         b = tr.model._infer(ids, gs, node_in, mask, session=sess).clone()
         c = tr.model._infer(ids, gs, node_in, mask).clone()               # no session: packs rebuilt
     assert torch.equal(b, c) and not torch.equal(a, b)
