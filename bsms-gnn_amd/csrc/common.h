@@ -98,4 +98,5 @@ struct bsms_plan {
   int32_t *ids = nullptr, *inv = nullptr;
   int32_t *block = nullptr, *pool_block = nullptr;   // the two device allocations the pointers above point into
   size_t block_cap = 0, pool_cap = 0;                // their capacities in bytes (plan.hip recycles them)
+  int device = 0;                                    // the device the blocks live on (current device at bsms_plan_create)
 };

@@ -91,18 +91,28 @@ namespace {
 // Index uploads go through a private non-blocking stream: a plain hipMemcpy is ordered behind everything the caller has
 // queued on the NULL stream (PyTorch's default), i.e. building the plans of a NEW mesh would drain the GPU first.  The
 // copy is complete on the host's timeline when upload_block returns, so kernels launched afterwards on any stream see it.
-hipStream_t upload_stream() {
-  static hipStream_t s = [] {
-    hipStream_t x = nullptr;
-    if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) x = nullptr;
-    return x;
-  }();
-  return s;
+constexpr int kMaxDevices = 64;
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
+std::mutex g_stream_mu;
+hipStream_t upload_stream() {   // one per device (a process normally drives one GPU; PyTorch callers may drive several)
+  static hipStream_t streams[kMaxDevices] = {};
+  static bool tried[kMaxDevices] = {};
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_stream_mu);
+  if (!tried[dev]) {
+    tried[dev] = true;
+    if (hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) streams[dev] = nullptr;
+  }
+  return streams[dev];
 }
 // Device blocks of destroyed plans are kept for the next plan: hipFree waits for the whole device, and a variable-mesh
 // training run retires L + 1 plans per step once the host-side cache is full.  (bsms_plan_destroy's contract: nothing that
 // uses the plan is still in flight -- the recycled block is overwritten by the next upload without further ordering.)
-struct PoolBlock { size_t cap; int32_t* ptr; };
+struct PoolBlock { size_t cap; int32_t* ptr; int dev; };
 std::mutex g_pool_mu;
 std::vector<PoolBlock> g_pool;
 size_t g_pool_bytes = 0;
@@ -112,8 +122,10 @@ int alloc_block(int32_t** dev, size_t bytes, size_t* cap) {
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
     int best = -1;
+    const int cur = current_device();
     for (int i = 0; i < (int)g_pool.size(); ++i)
-      if (g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + kBlockGrain && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
+      if (g_pool[i].dev == cur && g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + kBlockGrain &&
+          (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
     if (best >= 0) {
       *dev = g_pool[best].ptr;
       *cap = g_pool[best].cap;
@@ -126,12 +138,12 @@ int alloc_block(int32_t** dev, size_t bytes, size_t* cap) {
   BSMS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(dev), *cap));
   return BSMS_OK;
 }
-void release_block(int32_t* ptr, size_t cap) {
+void release_block(int32_t* ptr, size_t cap, int dev) {
   if (!ptr) return;
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
     if (g_pool.size() < kPoolMaxBlocks && g_pool_bytes + cap <= kPoolMaxBytes) {
-      g_pool.push_back(PoolBlock{cap, ptr});
+      g_pool.push_back(PoolBlock{cap, ptr, dev});
       g_pool_bytes += cap;
       return;
     }
@@ -216,6 +228,7 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
   }
 
   bsms_plan* p = new bsms_plan();
+  p->device = current_device();
   p->N = N;
   p->E = E;
   p->min_out_degree = min_deg;
@@ -253,7 +266,7 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
     h_ids[k] = (int32_t)ids[k];
     h_inv[ids[k]] = (int32_t)k;
   }
-  release_block(p->pool_block, p->pool_cap);
+  release_block(p->pool_block, p->pool_cap, p->device);
   p->pool_block = p->ids = p->inv = nullptr;
   p->Nk = 0;
   int rc;
@@ -266,8 +279,8 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
 
 extern "C" int bsms_plan_destroy(bsms_plan_t* p) {
   if (!p) return BSMS_OK;
-  release_block(p->block, p->block_cap);
-  release_block(p->pool_block, p->pool_cap);
+  release_block(p->block, p->block_cap, p->device);
+  release_block(p->pool_block, p->pool_cap, p->device);
   delete p;
   return BSMS_OK;
 }
