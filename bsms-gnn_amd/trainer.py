@@ -70,6 +70,30 @@ class FusedAdamW:
         self.step_count = int(sd["step"])
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _check_host_threads():
+    """PyTorch defaults to one intra-op thread per LOGICAL cpu; under a cgroup CPU quota (containers) the bursts of a few
+    CPU tensor copies per step then exhaust the quota and the scheduler parks the whole process for the rest of the
+    period -- 80 ms stalls on arbitrary lines of the training loop (profiles/fresh_mesh.py).  Warn once."""
+    import warnings
+    n = usable_cpus()
+    if torch.get_num_threads() > 2 * n:
+        warnings.warn(f"torch uses {torch.get_num_threads()} intra-op threads but this process may use ~{n} CPUs (cgroup quota / "
+                      f"affinity): call torch.set_num_threads({max(1, min(n, 8))}) to avoid CFS throttling stalls in the training loop",
+                      RuntimeWarning, stacklevel=3)
+
+
 class DevicePrefetcher:
     """`for batch in DevicePrefetcher(loader, trainer): trainer.iter(batch)` -- a background thread takes the host batches of
     `loader` one ahead of the training thread: uploads (pinned, on the copy stream), interning of the index tensors, and
@@ -136,6 +160,7 @@ class Trainer:
                                     max_grad_norm=opt_cfg.gnorm_clip)
         self.lr_scheduler = WarmupCosineDecay(opt_cfg.peak_lr, opt_cfg.warmup_steps, opt_cfg.decay_steps)
         self.train_step = 0
+        _check_host_threads()
         self._synced = False
         self._norm_base = None     # statistics every rank already shares (restore followed by warm-up)
 
