@@ -193,13 +193,16 @@ def plans_for(specs):
                 _BUILDERS = ThreadPoolExecutor(max_workers=8, thread_name_prefix="bsms-plan")
             if _GRAVE:
                 _reap()
-            built = list(_BUILDERS.map(lambda i: LevelPlan(*specs[i]), missing))
+    if len(missing) >= 2:                                  # built WITHOUT the lock: the training thread's lookups go on meanwhile
+        built = list(_BUILDERS.map(lambda i: LevelPlan(*specs[i]), missing))
+        with _LOCK:
             for i, plan in zip(missing, built):
-                g, _, ids = specs[i]
-                _CACHE._d[keys[i]] = (plan, g.untyped_storage(), ids.untyped_storage() if ids is not None else None)
+                if keys[i] not in _CACHE._d:               # (another thread may have built the same plan: the first one stays)
+                    g, _, ids = specs[i]
+                    _CACHE._d[keys[i]] = (plan, g.untyped_storage(), ids.untyped_storage() if ids is not None else None)
             while len(_CACHE._d) > _CACHE.capacity:
                 _CACHE._d.popitem(last=False)
-        return [_CACHE.get(g, n, ids) for g, n, ids in specs]
+    return [_CACHE.get(g, n, ids) for g, n, ids in specs]
 
 
 def clear_plan_cache():
@@ -252,16 +255,21 @@ def _upload(t, device):
     return t.to(device)
 
 
-def intern_index(t, device, shared_batch_axis=False):
+def _interned(key, src):
+    """The interned device tensor of `key` if its host original equals `src` (a digest match is confirmed by memcmp)."""
     with _LOCK:
-        return _intern_index(t, device, shared_batch_axis)
+        hit = _INTERNED.get(key)
+        if hit is not None:
+            _INTERNED.move_to_end(key)
+    return hit[0] if hit is not None and torch.equal(hit[1], src) else None
 
 
-def _intern_index(t, device, shared_batch_axis=False):
+def intern_index(t, device, shared_batch_axis=False):
     """Device copy of the CPU int64 index tensor `t`, shared between calls with equal content.
     shared_batch_axis: `t` is [B, ...] and the consumer reads t[0] only (consistent-mesh collate, models/model.py:190-192);
     when all B slices are equal only ONE slice is uploaded and the result is an expanded (stride-0) view, so the cache
-    does not pin B copies of the edge list in HBM."""
+    does not pin B copies of the edge list in HBM.
+    (The table is shared with trainer.DevicePrefetcher's thread: hashing, comparing and uploading run outside its lock.)"""
     if t.is_cuda or t.dtype != torch.int64:
         return t.to(device)
     first = None
@@ -269,28 +277,26 @@ def _intern_index(t, device, shared_batch_axis=False):
         # hot path (every step of a consistent-mesh loader): digest + memcmp of slice 0 only -- 1/B of the bytes; the
         # other slices were compared with slice 0 when this content was first seen, and the consumer reads t[0] only
         first = t[0]
-        key = (_content_key(first), t.shape[0], str(device))
-        hit = _INTERNED.get(key)
-        if hit is not None and torch.equal(hit[1], first):
-            _INTERNED.move_to_end(key)
-            return hit[0]
+        hit = _interned((_content_key(first), t.shape[0], str(device)), first)
+        if hit is not None:
+            return hit
         if not bool((t == t[:1]).all()):                   # slices differ: not a shared axis after all
             first = None
     key = (_content_key(first if first is not None else t), t.shape[0] if first is not None else -1, str(device))
     src = first if first is not None else t
-    hit = _INTERNED.get(key)
-    if hit is not None and torch.equal(hit[1], src):       # a digest match is confirmed on the content (host memcmp)
-        _INTERNED.move_to_end(key)
-        return hit[0]
+    hit = _interned(key, src)
+    if hit is not None:
+        return hit
     host = src.contiguous().clone()
     if first is not None:
         dev = _upload(host, device).unsqueeze(0).expand(t.shape[0], *first.shape)
     else:
         dev = _upload(host, device)
         dev._bsms_host = host                  # LevelPlan builds its CSR from the host original (no device read-back)
-    _INTERNED[key] = (dev, host)
-    if len(_INTERNED) > _cache_capacity():
-        _INTERNED.popitem(last=False)
+    with _LOCK:
+        _INTERNED[key] = (dev, host)
+        if len(_INTERNED) > _cache_capacity():
+            _INTERNED.popitem(last=False)
     return dev
 
 
