@@ -1516,6 +1516,33 @@ int edge_compute_waves() {
   static const int cw = NB >= 16 ? knob("BSMS_EDGE_CW16", 7) : knob("BSMS_EDGE_CW", 7);
   return cw;
 }
+// Compute waves of ONE edge launch.  A persistent workgroup runs ceil(tiles / grid) tiles one after the other and a tile
+// costs t0 + t1 * (rows per wave-set): the fixed part is the weight stream of the whole MLP, the rest scales with the rows.
+// Seven waves minimise the fixed part per row, but a launch whose last round is nearly empty pays a whole tile for it:
+// cylinder level 0 (90 112 rows, 512 slots) runs 2 rounds with 7, 6 waves and 3 with 5, 4 -- 6 waves win by the shorter
+// tile (same-box sweep: 4 / 5 / 6 / 7 waves = 400.1 / 392.6 / 404.4 / 397.2 steps/s, exactly this model's order).  The
+// slope t1 / t0 = 0.53 per wave with one row block per wave comes from the airfoil sweep (7 against 4 waves: +2.5 %).
+template <int NB, int RB>
+int pick_edge_waves(int64_t R) {
+  const int fixed = edge_compute_waves<NB>();
+#ifdef BSMS_EXPERIMENTS
+  if (getenv(NB >= 16 ? "BSMS_EDGE_CW16" : "BSMS_EDGE_CW") || getenv("BSMS_EDGE_CW_FIXED")) return fixed;
+#endif
+  const double slope = (NB >= 16 ? 0.25 : 0.53) * RB;
+  const int64_t slots = int64_t(device_cus()) * EdgeTile<NB, RB>::resident;
+  auto cost_of = [&](int cw) {
+    const int64_t tiles = ceil_div(R, int64_t(16) * RB * cw);
+    const int64_t per = ceil_div(tiles, std::min<int64_t>(tiles, slots));
+    return double(per) * (1.0 + slope * cw);
+  };
+  int best = fixed;
+  double best_cost = cost_of(fixed) * 0.92;   // the model is coarse: leave the measured default unless it predicts a clear gain
+  for (int cw = 6; cw >= 4; --cw) {
+    const double cost = cost_of(cw);
+    if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = cw; }
+  }
+  return best;
+}
 template <int NB>
 int edge_loader_waves() {
   static const int nl = NB >= 16 ? knob("BSMS_EDGE_NL16", 1) : knob("BSMS_EDGE_NL", 1);
@@ -1551,7 +1578,7 @@ int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
-  const int cw = edge_compute_waves<NB>();
+  const int cw = pick_edge_waves<NB, RB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
   pick_stream<NB>(a.ntiles, cw, edge_loader_waves<NB>(), a.nload, a.nring);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
@@ -1585,7 +1612,7 @@ int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
-  const int cw = edge_compute_waves<NB>();
+  const int cw = pick_edge_waves<NB, RB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
   pick_stream<NB>(a.ntiles, cw, edge_loader_waves<NB>(), a.nload, a.nring);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
