@@ -37,6 +37,7 @@ class LevelPlan:
     def __init__(self, g, num_nodes, ids=None, device=None):
         with _COUNT_LOCK:
             LevelPlan.constructed += 1
+            self.uid = LevelPlan.constructed      # never reused (unlike id()): cache keys built from it need not keep the plan alive
         g_cpu = _host_copy(g)
         if g_cpu.dim() != 2 or g_cpu.shape[0] != 2:
             raise ValueError(f"edge list must be [2, E], got {tuple(g_cpu.shape)}")

@@ -563,7 +563,7 @@ class InferenceSession:
             self.work = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             self.pkey = self.gkey = None
         pkey = (_PARAM_EPOCH[0], tuple((q.data_ptr(), q._version) for q in params))
-        gkey = (tuple(id(q) for q in plans), B, tuple(geom))
+        gkey = (tuple(q.uid for q in plans), B, tuple(geom))
         reuse = (1 if pkey == self.pkey and gkey == self.gkey else 0) | (2 if self.static_pos and gkey == self.gkey else 0)
         self.pkey, self.gkey = pkey, gkey
         return reuse
@@ -622,7 +622,7 @@ class BSGMP(nn.Module):
         """cal_ew chain of the down pass (BSMS.py:64,73,89).  It depends on the MESH only (w starts as ones, runs
         under no_grad and never sees h or pos), so it is computed once per hierarchy and cached on the level-0 plan;
         the reference recomputes it in every forward."""
-        key = tuple(id(p) for p in plans)
+        key = tuple(p.uid for p in plans)
         cache = getattr(plans[0], "_ew_chain", None) if plans else None
         if cache is not None and cache[0] == key:
             return cache[1]
@@ -633,7 +633,7 @@ class BSGMP(nn.Module):
                 ew, w_full = self.edge_conv.cal_ew(w, None, plan=plan)
                 w = w_full[ids]
                 ews.append(ew)
-            plans[0]._ew_chain = (key, ews, plans)               # keeps the keyed plans alive -> ids stay unique
+            plans[0]._ew_chain = (key, ews)                      # keyed by plan uids: no reference cycle through the plans
         return ews
 
     def prepare(self, m_ids, m_gs, n0, device):

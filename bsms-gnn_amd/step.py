@@ -123,7 +123,7 @@ class FusedStep:
     def _buffers(self, B, N, plans, dev):
         m, L = self.model, _abi.lib()
         C, p, D, H = m.cfg.out_dim, m.pos_dim, m.cfg.latent_dim, m.cfg.hidden_layer
-        key = (B, N, tuple(id(q) for q in plans), str(dev), m.process.precision)
+        key = (B, N, tuple(q.uid for q in plans), str(dev), m.process.precision)
         if key == self._shape_key:
             return self._buf
         R, depth = B * N, len(plans) - 1
