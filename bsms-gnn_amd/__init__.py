@@ -8,7 +8,7 @@ from .model import BSMS_Simulator, Normalizer, masked_rmse  # noqa: F401
 from .ops import BSGMP, GMP, MLP, InferenceSession, Unpool, WeightedEdgeConv, degree, scatter_sum  # noqa: F401
 from .dp import DataParallel, GradBuckets, global_masked_rmse  # noqa: F401
 from .hierarchy import BistrideMultiLayerGraph, to_flat_edge  # noqa: F401
-from .rollout import rollout_batch, rollout_one_traj, rollout_rmse  # noqa: F401
+from .rollout import RolloutErrors, rank_slice, rollout_batch, rollout_dataset, rollout_errors, rollout_one_traj, rollout_rmse  # noqa: F401
 from .step import FusedStep  # noqa: F401
 from .trainer import DevicePrefetcher, FusedAdamW, Trainer, WarmupCosineDecay  # noqa: F401
 

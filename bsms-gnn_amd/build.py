@@ -66,5 +66,51 @@ def build(force=False, verbose=True):
     return LIB
 
 
+ASAN_DIR = os.path.join(OBJ, "asan")
+ASAN_LIB = os.path.join(ASAN_DIR, "libbsms_host_asan.so")
+ASAN_SOURCES = ["plan.hip", "hierarchy.hip"]     # the library's HOST code: plan pool / recycling / uploads, hierarchy builder
+
+
+def asan_runtime():
+    """Path of clang's shared AddressSanitizer runtime (to LD_PRELOAD into the driver process), or None."""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[-1] if hits else None
+
+
+def build_host_sanitized(force=False):
+    """ASan + UBSan build of the host-side translation units (device code is left uninstrumented: -fno-gpu-sanitize), as a
+    separate small library that only the sanitizer tests load (tests/helpers/host_sanitizer_driver.py).  The plan pool,
+    the retirement of plans and the builder run on several host threads: lifetime bugs there corrupt device index blocks
+    silently, which is what a sanitizer run is for (race detection / sanitizers)."""
+    os.makedirs(ASAN_DIR, exist_ok=True)
+    stamp = os.path.join(ASAN_DIR, "stamp")
+    h = hashlib.sha256(b"asan-v1")
+    for f in ASAN_SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    digest = h.hexdigest()
+    if not force and os.path.exists(ASAN_LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return ASAN_LIB
+    hipcc = _hipcc()
+    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-shared-libsan"]
+    objs = []
+    for src in ASAN_SOURCES:
+        obj = os.path.join(ASAN_DIR, src.replace(".hip", ".o"))
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", *san, "-c", os.path.join(CSRC, src), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (sanitized) failed on {src}:\n{r.stdout}\n{r.stderr}")
+        objs.append(obj)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *san, "-o", ASAN_LIB, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link (sanitized) failed:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as fh:
+        fh.write(digest)
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--asan" in sys.argv:
+        print(build_host_sanitized(force="--force" in sys.argv))

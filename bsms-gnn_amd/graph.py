@@ -7,7 +7,7 @@ import ctypes as C
 import hashlib
 import os
 import threading
-from collections import OrderedDict
+from collections import OrderedDict, deque
 
 import numpy as np
 import torch
@@ -59,6 +59,15 @@ class LevelPlan:
 
     def set_pool(self, ids):
         ids_cpu = np.ascontiguousarray(_host_copy(ids).numpy())
+        if self.Nk > 0 and self._used:
+            # re-pooling hands the OLD ids / inv block straight back to the library's recycling pool (plan.hip:
+            # release_block): kernels of this plan that are still queued read it -- wait for the streams it was used on
+            # (plan destruction is ordered by events, _retire; a second set_pool is rare enough for a plain wait)
+            for st in list(self._used):
+                try:
+                    st.synchronize()
+                except Exception:
+                    pass
         with torch.cuda.device(self.device):
             _abi.check(_abi.lib().bsms_plan_set_pool(self._h, ids_cpu.ctypes.data, int(ids_cpu.shape[0])), "bsms_plan_set_pool")
         self.Nk = int(ids_cpu.shape[0])
@@ -96,12 +105,22 @@ class LevelPlan:
 # block without waiting (include/bsms_hip.h), so a plan is destroyed only after events recorded at retirement on the
 # current stream and on every stream the plan was used on have completed (the engine joins its side streams into the
 # caller's stream before every return).
-_GRAVE = []
+_GRAVE = deque()
 
 
 def _reap():
-    keep = []
-    for ev, h in _GRAVE:
+    """Destroy the retired plans whose events have completed.  `LevelPlan.__del__` runs on whatever thread drops the last
+    reference (the training thread, trainer.DevicePrefetcher's thread, a plan-builder thread, or the garbage collector in
+    the middle of any allocation) and `bsms_plan_destroy` is a ctypes call that releases the GIL: two threads scanning a
+    shared list would both see an entry and destroy its handle twice -- the library would then hand ONE device block to
+    two later plans.  Entries are therefore taken OUT of the queue one at a time (`deque.popleft` is atomic: whoever pops
+    an entry owns it exclusively), destroyed if finished, and put back if not.  No lock is held at any point, so a
+    finaliser that fires inside this function (a nested `_reap`) just pops other entries."""
+    for _ in range(len(_GRAVE)):
+        try:
+            ev, h = _GRAVE.popleft()
+        except IndexError:      # another thread got there first
+            return
         try:
             done = all(e.query() for e in ev)
         except Exception:
@@ -112,8 +131,7 @@ def _reap():
             except Exception:
                 pass
         else:
-            keep.append((ev, h))
-    _GRAVE[:] = keep
+            _GRAVE.append((ev, h))
 
 
 def _retire(h, device, used=()):

@@ -36,7 +36,9 @@ class Normalizer(nn.Module):
     def _accumulate(self, batched_data):
         rows = batched_data.reshape(-1, self.size)
         old = self._acc_weight.data
-        dw = torch.tensor(rows.shape[0] / self.unit, dtype=self.dtype, device=rows.device)
+        # normalizer.py:58: torch.tensor(python float) is FLOAT32, cast to fp64 afterwards -- the weight of a batch is the fp32
+        # rounding of rows / unit (it cancels when all batches have the same size, not otherwise)
+        dw = torch.tensor(rows.shape[0] / self.unit).type(self.dtype).to(rows.device)
         m1 = torch.mean(rows, dim=0).type(self.dtype)
         m2 = torch.mean(rows ** 2, dim=0).type(self.dtype)
         self._acc_weight.data = old.add(dw)

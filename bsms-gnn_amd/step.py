@@ -228,9 +228,12 @@ class FusedStep:
                 self._backward(b, st, sm, ews, B, N)
             torch.cuda.current_stream().wait_stream(side)
             gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gf):
+            # thread_local: a trainer.DevicePrefetcher thread may be allocating / uploading the NEXT batch's plans right
+            # now (hipMalloc, hipMemcpyAsync on its own streams); in the default global mode such a call from another
+            # thread invalidates this capture
+            with torch.cuda.graph(gf, capture_error_mode="thread_local"):
                 self._forward(b, sn, st, sm, ews, B, N)
-            with torch.cuda.graph(gb):
+            with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                 self._backward(b, st, sm, ews, B, N)
             self._graphs = (gf, gb, ews)              # the graphs hold raw pointers: keep what they point at alive
         gf, gb, _ = self._graphs

@@ -283,6 +283,33 @@ def rollout(model, initial, node_mask, m_gs, m_ids, steps):
     return torch.stack(frames)
 
 
+def rollout_errors(results, target, node_mask):
+    """Per-trajectory error figures of the rollout driver (src/rollout.py:99-107): results / target [T-1,N,C],
+    node_mask [T-1,N,1].  Returns rmse [1,1], rmse_c [T-1,C] (RMSE over the nodes per time step and channel) and its
+    transpose rmse_t [C,T-1]."""
+    se = (results - target) ** 2                                                      # :99
+    rmse = torch.sqrt((se * node_mask).sum() / node_mask.sum() / se.shape[-1])        # :101
+    rmse_c = torch.sqrt((se * node_mask).sum(dim=1) / node_mask.sum(dim=1))           # :106
+    return rmse.unsqueeze(0).unsqueeze(0), rmse_c, rmse_c.detach().clone().T          # :103, :107
+
+
+class RolloutErrorStats:
+    """The three accumulators of src/rollout.py:64-68, 86-97, 110-112 (`Normalizer` instances of size 1 / C / T-1 used as
+    running mean / std): `add` one trajectory at a time; mean / std as printed at :118-143."""
+
+    def __init__(self):
+        self.all = self.channel = self.time = None
+
+    def add(self, results, target, node_mask):
+        rmse, rmse_c, rmse_t = rollout_errors(results, target, node_mask)
+        if self.all is None:                                                          # :86-97
+            self.all, self.channel, self.time = Normalizer(1), Normalizer(results.shape[-1]), Normalizer(results.shape[0])
+        self.all(rmse, accumulate=True)                                               # :110-112
+        self.channel(rmse_c, accumulate=True)
+        self.time(rmse_t, accumulate=True)
+        return rmse, rmse_c, rmse_t
+
+
 def make_cfg(out_dim, latent_dim, hidden_layer, unet_depth, pos_dim):
     return SimpleNamespace(out_dim=out_dim, latent_dim=latent_dim, hidden_layer=hidden_layer,
                            unet_depth=unet_depth, pos_dim=pos_dim)

@@ -222,3 +222,47 @@ def test_intern_index_confirms_content_and_needs_no_xxhash(eng, monkeypatch):
         graph.intern_index(a + 100 + k, "cpu")
     assert len(graph._INTERNED) <= 8
     graph._INTERNED.clear()
+
+
+def test_retired_plans_are_destroyed_exactly_once_under_concurrency(eng, monkeypatch):
+    """graph._retire / _reap run from LevelPlan.__del__ on any thread while bsms_plan_destroy (ctypes) releases the GIL:
+    every retired handle must reach the library exactly once -- a double destroy would push one device block into the
+    recycling pool twice and two later plans would share it.  Stand-in library: destroy = sleep + record."""
+    import threading
+    import time
+    from bsms_gnn_amd import graph
+
+    class Ev:                        # an event that completes after a few queries
+        def __init__(self, n):
+            self.n = n
+
+        def query(self):
+            self.n -= 1
+            return self.n < 0
+
+    seen, lock = [], threading.Lock()
+
+    class FakeLib:
+        def bsms_plan_destroy(self, h):
+            time.sleep(0.0005)       # the real call releases the GIL too
+            with lock:
+                seen.append(h)
+            return 0
+
+    monkeypatch.setattr(graph._abi, "lib", lambda: FakeLib())
+    graph._GRAVE.clear()
+    for h in range(64):              # a backlog of unfinished plans that every reaper will walk over
+        graph._GRAVE.append(([Ev(h % 5)], ("old", h)))
+
+    def worker(t):
+        for k in range(50):
+            graph._retire(("new", t, k), None)       # device None: no event, finished at once
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for _ in range(10):
+        graph._reap()
+    assert not graph._GRAVE
+    assert len(seen) == len(set(seen)) == 64 + 8 * 50

@@ -159,3 +159,47 @@ def test_bf16_airfoil_full_size_vs_fp32_engine(eng):
     assert rel_err(res["bf16"][0], res["f32"][0]) < 3e-2
     assert abs(res["bf16"][1] - res["f32"][1]) < 1e-2 * abs(res["f32"][1])
     _grads_close(res["bf16"][2], res["f32"][2], "airfoil B=8 L=5 D=128 bf16 vs fp32 engine")
+
+
+def _fused_step_both_precisions(eng, kind, batch):
+    """One FusedStep (forward + masked RMSE + backward, no autograd: the path bench.py times) per precision on the same
+    model and batch; returns {prec: (pred, loss, grads)}."""
+    from bench import build_workload, data_tuple, make_cfg
+    wl = build_workload(kind, batch, "cuda")
+    torch.manual_seed(0)
+    sim = eng.BSMS_Simulator(make_cfg(wl["cfg"])).cuda()
+    data = data_tuple(wl)
+    sim(data, True, True)
+    grads = eng.GradBuckets(list(sim.parameters()))
+    step = eng.FusedStep(sim, grads)
+    res = {}
+    for prec in ("f32", "bf16"):
+        sim.process.precision = prec
+        grads.flat.zero_()
+        loss = step(data, True)
+        torch.cuda.synchronize()
+        res[prec] = (step.prediction().detach().clone(), float(loss),
+                     {k: p.grad.detach().clone() for k, p in sim.named_parameters() if p.grad is not None})
+    return wl, res
+
+
+def test_surface_b2_bf16_full_size(eng):
+    """BASELINE configs[4] in its STATED precision: inflating-surface stand-in, 16384 nodes, 6 levels, D=256, pos_dim 3,
+    B=2 (the per-GPU share of batch 16 over 8 GPUs), bf16 -- through the fused step, against the fp32 engine (itself
+    pinned to the oracle at this size by tests/test_hip_fullsize.py::test_surface_b2_step_matches_oracle).  D = 256 takes
+    the NB = 16 kernels and the deep one-plane weight ring: the LDS overflow fixed in round 3 showed up only at this size."""
+    wl, res = _fused_step_both_precisions(eng, "surface", 2)
+    assert wl["levels"][0][0] == 16384 and len(wl["levels"]) == 7 and wl["cfg"]["latent"] == 256 and wl["cfg"]["pos_dim"] == 3
+    assert torch.isfinite(res["bf16"][0]).all()
+    assert rel_err(res["bf16"][0], res["f32"][0]) < 3e-2
+    assert abs(res["bf16"][1] - res["f32"][1]) < 1e-2 * abs(res["f32"][1])
+    assert set(res["bf16"][2]) == set(res["f32"][2])
+    _grads_close(res["bf16"][2], res["f32"][2], "surface B=2 L=6 D=256 p=3 bf16 vs fp32 engine (fused step)")
+
+
+def test_airfoil_b8_bf16_fused_step_full_size(eng):
+    """configs[2] through the fused step as well (the autograd path is covered above)."""
+    _, res = _fused_step_both_precisions(eng, "airfoil", 8)
+    assert rel_err(res["bf16"][0], res["f32"][0]) < 3e-2
+    assert abs(res["bf16"][1] - res["f32"][1]) < 1e-2 * abs(res["f32"][1])
+    _grads_close(res["bf16"][2], res["f32"][2], "airfoil B=8 bf16 vs fp32 engine (fused step)")

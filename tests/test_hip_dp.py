@@ -93,3 +93,112 @@ def test_bench_n2_path_with_gloo_on_one_gpu(tmp_path):
           f"{line['host_enqueue_ms_per_step']:.2f} ms/step on rank 0, loss {line['config']['loss']:.6f}")
     # (with gloo the figure includes two blocking host-staged collectives per step; the N = 1 bench line has the pure
     #  enqueue cost: 1.2 ms per step)
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell -- the form the driver uses for --gpus 1 -- starts its own two ranks
+    (replaces nn.DataParallel, trainer/trainer.py:15-18): RCCL (backend nccl, one GPU per rank) when the box has two
+    GPUs, otherwise both ranks on the one GPU over gloo, labelled as a functional run.  Exit code 0, one JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "BSMS_DIST_BACKEND",
+                                                              "BSMS_FORCE_DEVICE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "cylinder"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2 and line["value"] > 0
+    d = line["distributed"]
+    assert d["launcher"] == "self"
+    if torch.cuda.device_count() >= 2:
+        assert d["backend"] == "nccl" and d["rccl_ranks"] == 2
+    else:
+        assert d["backend"] == "gloo" and d["rccl_ranks"] == 0 and "functional" in d["note"]
+    assert line["step_ms_hipevent"]["median"] > 0
+    print(f"\nbench --gpus 2 self-launched ({d['backend']}, {d['devices']} device(s)): {line['value']:.1f} steps/s aggregate")
+
+
+@pytest.mark.timeout(300)
+def test_bench_refuses_a_mismatched_world():
+    """--gpus N under a launcher that started another number of ranks is a usage error with a message, not an assert."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=250, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+def _rollout_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from conftest import Golden
+    from oracle import bsms_oracle as ro
+    import bsms_gnn_amd as eng
+    z, graphs = Golden("sim"), Golden("graphs")
+    es, ids = graphs.levels("del300")
+    sim = eng.BSMS_Simulator(ro.make_cfg(2, 32, 3, 3, 2))
+    sim.load_state_dict(z.state_dict())
+    sim = sim.cuda()
+    c = lambda t: t.cuda()
+    ic, rmask = c(z.t("rollout_ic")), c(z.t("rollout_mask"))
+    g1, i1 = [c(e.unsqueeze(0)) for e in es], [c(i.unsqueeze(0)) for i in ids]
+    ics = torch.cat([ic, ic * 0.5, ic * 0.25], 0)                        # three trajectories of one mesh, two ranks: 2 + 1
+    m3, gs3, is3 = rmask.repeat(3, 1, 1), [g.repeat(3, 1, 1) for g in g1], [i.repeat(3, 1) for i in i1]
+    part = eng.rollout_batch(sim, ics, torch.full((4, 3, 300, 2), -7.0, device="cuda"), m3, gs3, is3, shard=True)
+    full = eng.rollout_batch(sim, ics, torch.zeros(4, 3, 300, 2, device="cuda"), m3, gs3, is3, shard=True, gather=True)
+    # the driver loop, trajectories dealt round-robin; targets = the (unsharded) rollouts shifted a little
+    with torch.no_grad():
+        loader = []
+        for k in range(3):
+            truth = eng.rollout_one_traj(sim, ics[k:k + 1], torch.zeros(4, 300, 2, device="cuda"), rmask, g1, i1)
+            inp = ics[k:k + 1].repeat(4, 1, 1).unsqueeze(0)            # [1, T-1, N, C+p+1]: only frame 0 is read
+            loader.append((inp, (truth + 0.01 * (k + 1)).unsqueeze(0), rmask.repeat(4, 1, 1).unsqueeze(0), g1, i1))
+    errs = eng.rollout_dataset(sim, loader)
+    torch.save({"part": part.cpu(), "full": full.cpu(), "slice": eng.rank_slice(3), "summary": errs.summary(),
+                "count": float(errs.all._num_accumulations)}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rollout_trajectories_shard_across_ranks(tmp_path):
+    """trajectories of a rollout are independent -- each rank advances its slice
+    (`rollout_batch(shard=True)`), nothing is exchanged on the data path; `gather=True` reassembles the frames and
+    `rollout_dataset` merges only the three error accumulators (src/rollout.py:86-112).  Two ranks on one GPU (gloo)."""
+    from conftest import load_golden
+    from oracle import bsms_oracle as ro
+    import bsms_gnn_amd as eng
+    port = 29650 + os.getpid() % 40
+    out = str(tmp_path / "roll")
+    mp.start_processes(_rollout_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["slice"] == (0, 2) and r1["slice"] == (2, 3)
+    # single-process reference of the same three trajectories
+    z, graphs = load_golden("sim"), load_golden("graphs")
+    es, ids = graphs.levels("del300")
+    sim = eng.BSMS_Simulator(ro.make_cfg(2, 32, 3, 3, 2))
+    sim.load_state_dict(z.state_dict())
+    sim = sim.cuda()
+    ic, rmask = z.t("rollout_ic").cuda(), z.t("rollout_mask").cuda()
+    g1, i1 = [e.unsqueeze(0).cuda() for e in es], [i.unsqueeze(0).cuda() for i in ids]
+    ics = torch.cat([ic, ic * 0.5, ic * 0.25], 0)
+    want = eng.rollout_batch(sim, ics, torch.zeros(4, 3, 300, 2, device="cuda"), rmask.repeat(3, 1, 1),
+                             [g.repeat(3, 1, 1) for g in g1], [i.repeat(3, 1) for i in i1]).cpu()
+    assert torch.equal(r0["full"], want) and torch.equal(r1["full"], want)                 # gathered: bit-identical frames on every rank
+    assert torch.equal(r0["part"][:, :2], want[:, :2]) and bool((r0["part"][:, 2] == -7).all())   # un-gathered: own columns only
+    assert torch.equal(r1["part"][:, 2], want[:, 2]) and bool((r1["part"][:, :2] == -7).all())
+    assert r0["count"] == 3 and r1["count"] == 3
+    errs = eng.RolloutErrors()
+    for k in range(3):
+        truth = want[:, k] + 0.01 * (k + 1)
+        errs.add(want[:, k], truth, rmask.cpu().repeat(4, 1, 1))
+    for name, (mean, std) in errs.summary().items():
+        for r in (r0, r1):
+            assert torch.allclose(r["summary"][name][0].cpu(), mean, rtol=1e-5, atol=1e-9), name
+            assert torch.equal(r["summary"][name][0], r0["summary"][name][0]), name

@@ -16,11 +16,15 @@ Tolerances (BASELINE.json north_star: 1e-5 relative fp32)
     and which side of the kink they land on differs between ANY two fp32 summation orders -- so "GPU within 1e-5 of
     CPU fp32" is not a property even two runs of the reference on different BLAS builds have.  What is required:
         e_gpu(p) = max|g_gpu - g_64| / max|g_64| ,  e_cpu(p) likewise for the fp32 oracle
-        (a) worst tensor:    max_p e_gpu            <= max(1e-5, 3 * max_p e_cpu)
-        (b) typical tensor:  median_p e_gpu         <= max(1e-5, 2 * median_p e_cpu)
-        (c) tail:            90th percentile e_gpu  <= max(1e-5, 2 * 90th percentile e_cpu)
+        (a) worst tensor:    max_p e_gpu            <= max(1e-5, 1.5 * max_p e_cpu)
+        (b) typical tensor:  median_p e_gpu         <= max(1e-5, 1.5 * median_p e_cpu)
+        (c) tail:            90th percentile e_gpu  <= max(1e-5, 1.5 * 90th percentile e_cpu)
+        (d) regression guard on the DIRECT distance: median_p max|g_gpu - g_cpu32| / max|g_cpu32| <= max(1e-5, 2.5 * median_p e_cpu)
+            (triangle inequality: two fp32 paths that are each e away from the exact gradient are at most 2e apart)
     i.e. the engine's distance to the exact gradient has the same distribution over the parameter tensors as the
-    reference's own fp32 path.  A per-tensor ratio is not meaningful (which tensors a near-zero ReLU input lands in is
+    reference's own fp32 path.  (Rounds 1-3 allowed 3x / 2x / 2x; the measured ratios are 1.0-1.4 on the BASELINE
+    configurations.  The depth-7 strip at B=4 -- few rows per coarse level, so few independent kink events -- measured a
+    median ratio of 1.63 and keeps 2x for (b).)  A per-tensor ratio is not meaningful (which tensors a near-zero ReLU input lands in is
     random for both implementations), and the factors allow for the fact that ONE flipped mask perturbs the gradient
     of every layer upstream of it, so the per-tensor errors of a run are strongly correlated (few independent events).
     Measured on MI355X (gpu | cpu32, worst / median): airfoil B=8 9.4e-5 / 1.0e-5 | 9.3e-5 / 8.1e-6; cylinder B=8
@@ -102,7 +106,7 @@ def run_config(eng, kind, batch, layout, mesh=None, cfg=None):
                 gg=gg, g32=g32, g64=g64, t32=t32, t64=t64, levels=wl["levels"])
 
 
-def check(r, tag):
+def check(r, tag, f_worst=1.5, f_median=1.5, f_p90=1.5, f_direct=2.5):
     # ---- forward: element-wise and max-norm, against the fp32 oracle
     a, b = r["pred"].double(), r["pred32"].double()
     scale, rms = float(b.abs().max()), float(b.pow(2).mean().sqrt())
@@ -124,9 +128,10 @@ def check(r, tag):
           f"  grads vs fp64 over {len(keys)} tensors: gpu worst {e_gpu.max():.2e} ({keys[worst]}) median {np.median(e_gpu):.2e} | "
           f"cpu32 worst {e_cpu.max():.2e} median {np.median(e_cpu):.2e} | gpu-vs-cpu32 worst {direct.max():.2e} "
           f"median {np.median(direct):.2e} | p90 gpu {p90g:.2e} cpu32 {p90c:.2e}")
-    assert e_gpu.max() <= max(1e-5, 3 * e_cpu.max()), (tag, "worst tensor", keys[worst], e_gpu.max(), e_cpu.max())
-    assert np.median(e_gpu) <= max(1e-5, 2 * np.median(e_cpu)), (tag, "median", np.median(e_gpu), np.median(e_cpu))
-    assert p90g <= max(1e-5, 2 * p90c), (tag, "90th percentile", p90g, p90c)
+    assert e_gpu.max() <= max(1e-5, f_worst * e_cpu.max()), (tag, "worst tensor", keys[worst], e_gpu.max(), e_cpu.max())
+    assert np.median(e_gpu) <= max(1e-5, f_median * np.median(e_cpu)), (tag, "median", np.median(e_gpu), np.median(e_cpu))
+    assert p90g <= max(1e-5, f_p90 * p90c), (tag, "90th percentile", p90g, p90c)
+    assert np.median(direct) <= max(1e-5, f_direct * np.median(e_cpu)), (tag, "gpu-vs-cpu32 median", np.median(direct), np.median(e_cpu))
 
 
 @pytest.fixture(scope="module")
@@ -166,4 +171,4 @@ def test_airfoil_depth7_reference_default(eng):
     w, mesh = strip_mesh(327, 16, 7)
     r = run_config(eng, "airfoil", 4, "dense", mesh=mesh, cfg=w)
     assert len(r["levels"]) == 8 and r["levels"][0][0] == 5232 and r["levels"][-1][0] >= 2
-    check(r, "airfoil-sized strip B=4 L=7 (reference default depth)")
+    check(r, "airfoil-sized strip B=4 L=7 (reference default depth)", f_median=2.0)
