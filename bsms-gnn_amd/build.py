@@ -72,37 +72,40 @@ ASAN_SOURCES = ["plan.hip", "hierarchy.hip"]     # the library's HOST code: plan
 
 
 def asan_runtime():
-    """Path of clang's shared AddressSanitizer runtime (to LD_PRELOAD into the driver process), or None."""
-    import glob
-    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
-    return hits[-1] if hits else None
+    """Path of GCC's shared AddressSanitizer runtime (LD_PRELOADed into the torch-free driver process), or None.
+    GCC's, not the one shipped with ROCm's clang: that runtime intercepts hsa_amd_memory_pool_allocate for DEVICE-side
+    ASan (needs xnack) and makes every hipMalloc fail with 'out of memory' on this platform."""
+    r = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True)
+    path = os.path.realpath(r.stdout.strip()) if r.returncode == 0 else ""
+    return path if path and os.path.isabs(path) and os.path.exists(path) else None
 
 
 def build_host_sanitized(force=False):
-    """ASan + UBSan build of the host-side translation units (device code is left uninstrumented: -fno-gpu-sanitize), as a
-    separate small library that only the sanitizer tests load (tests/helpers/host_sanitizer_driver.py).  The plan pool,
-    the retirement of plans and the builder run on several host threads: lifetime bugs there corrupt device index blocks
-    silently, which is what a sanitizer run is for (race detection / sanitizers)."""
+    """ASan + UBSan build of the library's host-only translation units (plan.hip, hierarchy.hip contain no device code)
+    with g++ as plain C++ against the HIP runtime API, as a separate small library that only the sanitizer tests load
+    (tests/helpers/host_sanitizer_driver.py).  The plan pool, the retirement of plans and the builder run on several host
+    threads: lifetime bugs there corrupt device index blocks silently, which is what a sanitizer run is for (SURVEY.md
+    section 5: race detection / sanitizers)."""
     os.makedirs(ASAN_DIR, exist_ok=True)
     stamp = os.path.join(ASAN_DIR, "stamp")
-    h = hashlib.sha256(b"asan-v1")
+    h = hashlib.sha256(b"asan-gcc-v2")
     for f in ASAN_SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     digest = h.hexdigest()
     if not force and os.path.exists(ASAN_LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
         return ASAN_LIB
-    hipcc = _hipcc()
-    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-shared-libsan"]
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     objs = []
     for src in ASAN_SOURCES:
         obj = os.path.join(ASAN_DIR, src.replace(".hip", ".o"))
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", *san, "-c", os.path.join(CSRC, src), "-o", obj],
-                           capture_output=True, text=True)
+        r = subprocess.run(["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", *san,
+                            "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc (sanitized) failed on {src}:\n{r.stdout}\n{r.stderr}")
+            raise RuntimeError(f"g++ (sanitized) failed on {src}:\n{r.stdout}\n{r.stderr}")
         objs.append(obj)
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *san, "-o", ASAN_LIB, *objs], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-shared", "-fPIC", *san, "-o", ASAN_LIB, *objs, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link (sanitized) failed:\n{r.stdout}\n{r.stderr}")
     with open(stamp, "w") as fh:

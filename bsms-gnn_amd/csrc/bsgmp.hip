@@ -238,6 +238,14 @@ extern "C" int bsms_bsgmp_bwd_ex(const bsms_plan_t* const* plans, const float* c
                                  const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                                  const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
                                  int precision, int flags, bsms_stream_t stream) {
+  return bsms_bsgmp_bwd_ev(plans, ew, L, h, pos, grad_out, B, D, p, pos_batch_stride, hidden, params, saved, work, grad_h, grads,
+                           precision, flags, nullptr, stream);
+}
+
+extern "C" int bsms_bsgmp_bwd_ev(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                                 const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                                 const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
+                                 int precision, int flags, void* const* block_done_events, bsms_stream_t stream) {
   Shape s;
   int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_bwd");
   if (rc) return rc;
@@ -269,10 +277,19 @@ extern "C" int bsms_bsgmp_bwd_ex(const bsms_plan_t* const* plans, const float* c
     const int slot = nblk & 1;
     int r;
     if (marked[slot] && ((!gmp_marks_chained() && (r = side_wait_mark(lane0, slot, st))) || (r = side_wait_mark(lane1, slot, st)))) return r;
+    const int order = nblk;   // position of this block in the backward's execution order
     ++nblk;
     marked[slot] = true;
-    return gmp_bwd_core(plans[level], x, pos_l[level], g_in, B, D, p, pstride_l[level], hidden, block(params, k, hidden), v.gmp[k],
-                        slot ? w.gmp_b : w.gmp, gx, block(grads, k, hidden), slot, st, precision);
+    if ((r = gmp_bwd_core(plans[level], x, pos_l[level], g_in, B, D, p, pstride_l[level], hidden, block(params, k, hidden), v.gmp[k],
+                          slot ? w.gmp_b : w.gmp, gx, block(grads, k, hidden), slot, st, precision))) return r;
+    // Gradient-bucket hand-off (bsms_bsgmp_bwd_ev): lane 1's mark of this block covers lane 0's (gmp_marks_chained) and both
+    // lanes are in-order streams, so an event recorded on lane 1 HERE completes when every weight gradient of this block,
+    // of the blocks before it and of anything queued on the lanes earlier (a deferred bsms_mlp_bwd_ex) has been written.
+    if (block_done_events && block_done_events[order]) {
+      if (!gmp_marks_chained() && (r = side_wait_mark(lane0, slot, lane1->stream))) return r;
+      BSMS_HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(block_done_events[order]), lane1->stream));
+    }
+    return BSMS_OK;
   };
   // up path, last block first.  The gradient reaching level d is both the up block's grad_out and the gradient of
   // the skip connection s_d: it stays in w.skip[d] until the down path picks it up.

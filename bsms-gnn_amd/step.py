@@ -60,6 +60,8 @@ class FusedStep:
         self.model, self.grads, self.group, self.use_graph = model, grads, group, use_graph
         self._shape_key, self._graphs, self._ptr_guard = None, None, None
         self._arena = _Arena()
+        self._overlap = None          # bucket schedule of the overlapped gradient all-reduce (_bucket_schedule), built lazily
+        self._comm = None             # communication stream the bucket all-reduces are issued from
         for p in grads.params:                      # .grad aliases the flat buffer once and for all
             off, n = grads._slot[p]
             p.grad = grads.flat[off:off + n].view_as(p)
@@ -167,7 +169,8 @@ class FusedStep:
                                no._E_data.data_ptr(), no._E_data_squared.data_ptr(), no.std_eps.data_ptr(), b["pred"].data_ptr(),
                                None, None, b["sums"].data_ptr(), work.data_ptr(), s), "bsms_sim_epilogue")
 
-    def _backward(self, b, tar, mask, ews, B, N):
+    def _backward(self, b, tar, mask, ews, B, N, events=None):
+        """`events`: (pointer array, keep-alive) of 2L+1 hipEvent_t for bsms_bsgmp_bwd_ev, or None."""
         m, L, s = self.model, _abi.lib(), _stream()
         C, p, D, H = m.cfg.out_dim, m.pos_dim, m.cfg.latent_dim, m.cfg.hidden_layer
         R, t = b["R"], self._tabs
@@ -182,9 +185,9 @@ class FusedStep:
         ewp, keep = _abi.ptr_array([e.data_ptr() for e in ews])
         # BSMS_BWD_DEFER_JOIN: the weight gradients of the last (level-0) block are still running on the engine's side
         # streams (~0.2 ms on half the chip) while the encoder's backward -- own scratch, own gradient slots -- runs here
-        ck(L.bsms_bsgmp_bwd_ex(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), b["gh1"].data_ptr(), B, D, p, N * p, H,
+        ck(L.bsms_bsgmp_bwd_ev(b["pl"], ewp, b["depth"], b["h0"].data_ptr(), b["pos"].data_ptr(), b["gh1"].data_ptr(), B, D, p, N * p, H,
                                t["proc"][0][0], b["s_proc"].data_ptr(), work.data_ptr(), b["gh0"].data_ptr(), t["proc"][1][0],
-                               PRECISIONS[b["prec"]], 1, s), "bsms_bsgmp_bwd")
+                               PRECISIONS[b["prec"]], 1, None if events is None else events[0], s), "bsms_bsgmp_bwd")
         ck(L.bsms_mlp_bwd(b["norm_in"].data_ptr(), b["gh0"].data_ptr(), R, C + 1, D, D, H, 1, t["enc"][0][0], b["s_enc"].data_ptr(),
                           b["work_enc"].data_ptr(), None, t["enc"][1][0], s), "bsms_mlp_bwd(encode)")
         ck(L.bsms_side_lanes_join(s), "bsms_side_lanes_join")
@@ -205,10 +208,73 @@ class FusedStep:
         self._forward(b, node_in, tar, mask, ews, B, N)
         if world > 1:
             dist.all_reduce(b["sums"], op=dist.ReduceOp.SUM, group=self.group)
-        self._backward(b, tar, mask, ews, B, N)
-        if world > 1:
-            dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if world > 1 and self.overlap_allreduce:
+            self._backward_overlapped(b, tar, mask, ews, B, N)
+        else:
+            self._backward(b, tar, mask, ews, B, N)
+            if world > 1:
+                dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
         return b["loss"][0].clone()       # the static buffer is overwritten by the next step: hand out a copy (4 bytes)
+
+    # ------------------------------------------------------------------------------------------------ overlapped all-reduce
+    overlap_allreduce = True      # False: ONE all-reduce of the whole flat buffer after the backward (rounds 1-3)
+
+    def _bucket_schedule(self, depth):
+        """Which `block_done_events` entry of bsms_bsgmp_bwd_ev releases each bucket of `self.grads`.
+        The backward produces the weight gradients in this order: decoder (deferred onto side lane 0 in front of the U-Net),
+        the U-Net blocks in EXECUTION order e = 0..2L -- up_gmps[L-1] .. up_gmps[0], bottom_gmp, down_gmps[L-1] .. down_gmps[0]
+        -- and the encoder (on the caller's stream, after which the lanes are joined).  The flat gradient buffer is laid out
+        in reversed parameter order (dp.GradBuckets), i.e. roughly in this order too, so consecutive buckets complete
+        one after the other.  A bucket is released by the LAST stage any of its parameters belongs to; `None` = only the
+        final join (encoder, and whatever shares a bucket with it)."""
+        m, L = self.model, depth
+        stage = {}
+        for q in m.decode.flat_params():
+            stage[q] = 0                                          # covered by the first block's event (in-order lanes)
+        blocks = [*m.process.down_gmps, m.process.bottom_gmp, *m.process.up_gmps]
+        for k, blk in enumerate(blocks):
+            e = (2 * L - k) if k < L else (L if k == L else L - 1 - (k - (L + 1)))     # storage index -> execution index
+            for q in (*blk.mlp_node.flat_params(), *blk.mlp_edge.flat_params()):
+                stage[q] = e
+        out = []
+        for bk in self.grads.buckets:
+            st = [stage.get(q) for q in bk["params"]]
+            out.append(None if any(v is None for v in st) else max(st))
+        return out
+
+    def _backward_overlapped(self, b, tar, mask, ews, B, N):
+        """The backward with the gradient all-reduce issued PER BUCKET from a communication stream that waits for the
+        side-lane event after which the bucket's gradients are final -- the ring transfer of the decoder / up-path buckets
+        runs under the down-path blocks; only the last bucket (first down block + encoder) is exposed after the join.
+        The host enqueues the whole backward first (it runs ~4 ms ahead of the GPU), then the waits + all-reduces: they
+        execute on the GPU as soon as their event fires, not when the host gets there.  Every rank issues the same
+        collectives in the same order (the schedule depends on the model only); sums are bitwise rank-independent."""
+        depth = b["depth"]
+        if self._overlap is None or self._overlap["depth"] != depth:
+            evs = [torch.cuda.Event() for _ in range(2 * depth + 1)]
+            for e in evs:
+                e.record()                     # materialises the hipEvent_t (torch creates it on first use)
+            sched = self._bucket_schedule(depth)
+            used = {e for e in sched if e is not None}
+            ptrs = [evs[i].cuda_event if i in used else None for i in range(2 * depth + 1)]
+            self._overlap = dict(depth=depth, events=evs, sched=sched, ptrs=_abi.ptr_array(ptrs))
+            self._comm = torch.cuda.Stream(device=b["h0"].device)
+        ov = self._overlap
+        self._backward(b, tar, mask, ews, B, N, events=ov["ptrs"])        # ends with bsms_side_lanes_join on the caller's stream
+        main = torch.cuda.current_stream()
+        works = []
+        with torch.cuda.stream(self._comm):
+            for bk, e in zip(self.grads.buckets, ov["sched"]):
+                if e is None:
+                    continue
+                self._comm.wait_event(ov["events"][e])
+                works.append(dist.all_reduce(bk["view"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for bk, e in zip(self.grads.buckets, ov["sched"]):               # what only the final join releases
+            if e is None:
+                works.append(dist.all_reduce(bk["view"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()                           # the caller's stream waits for the collectives (no host block with nccl)
+        main.wait_stream(self._comm)
 
     def prediction(self):
         """[B,N,C] prediction of the last step (a static buffer: clone it to keep it)."""

@@ -221,6 +221,17 @@ int bsms_bsgmp_bwd_ex(const bsms_plan_t* const* plans, const float* const* ew, i
                       const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                       const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
                       int precision, int flags, bsms_stream_t stream);
+/* bsms_bsgmp_bwd_ex with a hand-off for data-parallel callers that all-reduce their gradients in buckets WHILE the backward is
+ * still running (the reference never got there: trainer/trainer.py:15-18 wraps nn.DataParallel and
+ * train.py:16 disables it).  `block_done_events`: nullable HOST array of 2L+1 hipEvent_t (entries may be NULL), indexed by the
+ * position of a block in the backward's EXECUTION order -- up_gmps[L-1] .. up_gmps[0] (levels 0 .. L-1), bottom_gmp,
+ * down_gmps[L-1] .. down_gmps[0].  Event e is recorded on an internal side stream at the point where every weight gradient
+ * of blocks 0..e -- and of a bsms_mlp_bwd_ex(BSMS_BWD_DEFER_JOIN) issued before this call -- has been written to `grads`:
+ * a communication stream that waits for it may read those slots.  The events are the caller's (created without timing). */
+int bsms_bsgmp_bwd_ev(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
+                      const float* grad_out, int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
+                      const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
+                      int precision, int flags, void* const* block_done_events, bsms_stream_t stream);
 int bsms_side_lanes_join(bsms_stream_t stream);
 /* bsms_mlp_bwd with `flags`.  BSMS_BWD_DEFER_JOIN: `grad_x` is complete in stream order when the call returns, the weight
  * gradients run on an internal side stream; same contract as above (`work`, `grads`, bsms_side_lanes_join). */

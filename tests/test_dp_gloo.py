@@ -108,3 +108,29 @@ def test_two_rank_gradients_match_single_process(tmp_path):
     assert abs(float(r0["norm"]) - float(r0["ref_flat"].norm())) < 1e-4 * float(r0["ref_flat"].norm())
     for r in (r0, r1):                                                                     # shared base counted once
         torch.testing.assert_close(r["base_merge"], r["base_seq"], rtol=1e-12, atol=1e-15)
+
+
+def test_bucket_schedule_follows_the_backward_execution_order():
+    """step.FusedStep._bucket_schedule: every gradient bucket is released by the bsms_bsgmp_bwd_ev event of the LAST U-Net
+    block (in execution order: up_gmps[L-1] .. up_gmps[0], bottom_gmp, down_gmps[L-1] .. down_gmps[0]) any of its
+    parameters belongs to; buckets holding encoder parameters wait for the final join.  Host logic only (no launch)."""
+    from types import SimpleNamespace
+    import bsms_gnn_amd as eng
+    L = 3
+    cfg = SimpleNamespace(out_dim=2, latent_dim=32, hidden_layer=2, unet_depth=L, pos_dim=2)
+    sim = eng.BSMS_Simulator(cfg)
+    grads = eng.GradBuckets(list(sim.parameters()), bucket_bytes=16 << 10)
+    step = eng.FusedStep(sim, grads)
+    sched = step._bucket_schedule(L)
+    assert len(sched) == len(grads.buckets) > 4
+    name = {p: k for k, p in sim.named_parameters()}
+    exec_order = [f"process.up_gmps.{i}" for i in range(L - 1, -1, -1)] + ["process.bottom_gmp"] + \
+                 [f"process.down_gmps.{i}" for i in range(L - 1, -1, -1)]
+    for bk, e in zip(grads.buckets, sched):
+        names = [name[p] for p in bk["params"]]
+        if any(n.startswith("encode.") for n in names):
+            assert e is None
+            continue
+        want = max(0 if n.startswith("decode.") else next(i for i, pre in enumerate(exec_order) if n.startswith(pre + ".")) for n in names)
+        assert e == want, (names[0], e, want)
+    assert sched[0] is not None and sched[-1] is None          # the decoder's bucket goes first, the encoder's last

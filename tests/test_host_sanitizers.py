@@ -1,7 +1,7 @@
 """ASan + UBSan over the library's HOST code (csrc/plan.hip: plan upload / block recycling pool / re-pooling;
 csrc/hierarchy.hip: the bi-stride builder, reference graph_wrappers/bsms_graph_wrapper.py:8-154): the sanitized build
 (bsms-gnn_amd/build.py: build_host_sanitized) is driven by tests/helpers/host_sanitizer_driver.py in a torch-free process
-under LD_PRELOAD of the ASan runtime; any report fails the test.  CPU: the hierarchy builder and the error path of
+under LD_PRELOAD of GCC's ASan runtime (g++ compiles the two host-only files as plain C++); any report fails the test.  CPU: the hierarchy builder and the error path of
 bsms_plan_create.  GPU box (-m gpu): the whole plan life cycle incl. recycling and six concurrent host threads."""
 import importlib.util
 import os
@@ -20,8 +20,8 @@ def _build():
     spec.loader.exec_module(mod)
     rt = mod.asan_runtime()
     if rt is None:
-        pytest.skip("clang's shared ASan runtime not found under /opt/rocm")
-    if os.path.exists(mod.ASAN_LIB) and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("GCC's shared ASan runtime (libasan.so) not found")
+    if os.path.exists(mod.ASAN_LIB) and subprocess.run(["which", "g++"], capture_output=True).returncode != 0:
         return mod.ASAN_LIB, rt                         # prebuilt library travelled here, no compiler needed
     return mod.build_host_sanitized(), rt
 
