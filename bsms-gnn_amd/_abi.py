@@ -16,6 +16,7 @@ SIGNATURES = {
     "bsms_last_error": (C.c_char_p, []),
     "bsms_plan_create": (c_int, [c_void_p, c_i64, c_i64, PP]),
     "bsms_plan_set_pool": (c_int, [c_void_p, c_void_p, c_i64]),
+    "bsms_plan_bind_edge_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
     "bsms_plan_destroy": (c_int, [c_void_p]),
     "bsms_plan_pool_trim": (c_int, []),
     "bsms_plan_num_nodes": (c_i64, [c_void_p]),

@@ -575,11 +575,37 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
     if (paired) store_pair_stream<NB>(act, store_base, row, nrows, lane, 2 * c, streaming);
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
     // Two accumulators interleaved so that back-to-back MFMAs are independent.
-    if constexpr (LONE) {
-      // A launch of one round of workgroups has a single wave per SIMD; with a fragment read right in front of its MFMAs
-      // that wave sat out an LDS round trip per pair (~350 cycles per six MFMAs: the "24 us floor" of every node-level
-      // launch at the coarse levels).  Here pairs are read ONE PAIR AHEAD (f = current, n = next), pinned by
-      // sched_barrier.  (With two or three waves per SIMD the compiler's own order is faster: the other variant.)
+    if constexpr (LONE && NB == 8) {
+      // A launch of one round of workgroups has a single wave per SIMD: nothing hides its stalls.  Measured per stage of
+      // the node MLP at the coarse levels (profiles/lone_timeline.py): 3.0k cycles for the 96 MFMAs of a stage (31 each,
+      // against 17 back to back) with fragments read ONE pair ahead -- an LDS round trip (~200 cycles for a lone wave)
+      // is longer than the four MFMAs that were supposed to cover it -- and with only two accumulator chains in flight.
+      // Here the 2 NB fragments of the chunk are requested at once (64 VGPRs of the 256-register budget; the MFMAs
+      // consume them in request order behind counted lgkmcnt waits) and four accumulator chains interleave.  The three
+      // products of an accumulator keep their order (h_w l_x, h_w h_x, l_w h_x): bit-identical results.
+      float4 fh[NB], fl[NB];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        fh[t] = body[(t * 2) * 64];
+        fl[t] = body[(t * 2 + 1) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NB; t += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[t + k] = mma(fh[t + k], bl[c], (ZERO && c == 0) ? zero : acc[t + k]);
+        if (t == 0) {   // VALU work for later, placed among this chunk's MFMAs
+          if (c + 1 < R::NCH) split_block<NB>(act, c + 1, rs.s, bh[c + 1], bl[c + 1]);
+          else if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[t + k] = mma(fh[t + k], bh[c], acc[t + k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[t + k] = mma(fl[t + k], bh[c], acc[t + k]);
+      }
+    } else if constexpr (LONE) {
+      // (D = 256: the fragments of a whole chunk do not fit next to 64 + 64 activation / accumulator registers)
+      // pairs are read ONE PAIR AHEAD (f = current, n = next), pinned by sched_barrier.
       float4 f0 = body[0], f1 = body[2 * 64];                                      // (t = 0, plane h)
 #pragma unroll
       for (int t = 0; t < NB; t += 2) {
@@ -709,10 +735,15 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   }
 
   f32x4 act[NB], acc[NB];
+  // single-round launches (256-register budget, nothing to overlap a memory round trip with): the second source of a Linear
+  // over [x, x2] is requested together with the first and stays in registers (the multi-round variants re-read it twice)
+  constexpr bool KEEP2 = LONE && IN == IN_ROWS2 && NB == 8;
+  f32x4 x2t[KEEP2 ? NB : 1];
 
   // ---- input stage
   if (IN == IN_ROWS || IN == IN_ROWS2) {
     load_rows<NB>(act, a.x + rowc * D, lg);
+    if constexpr (KEEP2) load_rows<NB>(x2t, a.x2 + rowc * D, lg);
   } else if (IN == IN_SMALL) {
     load_features<NB>(act, a.bias_in, lg);
     for (int k = 0; k < a.K0; ++k) axpy_features<NB>(act, w0t + k * D, a.x[rowc * a.K0 + k], lg);
@@ -785,13 +816,24 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
       // read once more for it -- node-level rows, L2-resident) and one weight scale (PackDesc::mate), so the second half
       // continues the raw sums of the first; the bias rides in the second pack
       float m = row_amax<NB>(act);
-      load_rows<NB>(acc, a.x2 + rowc * D, lg);
-      m = fmaxf(m, row_amax<NB>(acc));
+      stamp();          // (timing builds) x has arrived
+      if constexpr (KEEP2) {
+        m = fmaxf(m, row_amax<NB>(x2t));
+      } else {
+        load_rows<NB>(acc, a.x2 + rowc * D, lg);
+        m = fmaxf(m, row_amax<NB>(acc));
+      }
+      stamp();          // x2 has arrived
       note_amax(brow, 0, m, lane);
       const RowScale rs = scale_of(m);
       mfma_stage<NB, true, 0, LONE>(acc, act, rs, ring, slot, lane);
-      load_rows<NB>(act, a.x2 + rowc * D, lg);
-      mfma_stage<NB, false, 2, LONE>(acc, act, rs, ring, slot, lane);
+      stamp();          // first half of stage 0
+      if constexpr (KEEP2) {
+        mfma_stage<NB, false, 2, LONE>(acc, x2t, rs, ring, slot, lane);
+      } else {
+        load_rows<NB>(act, a.x2 + rowc * D, lg);
+        mfma_stage<NB, false, 2, LONE>(acc, act, rs, ring, slot, lane);
+      }
     } else {
       const float m = row_amax<NB>(act);
       note_amax(brow, l, m, lane);
@@ -816,6 +858,13 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
 
   // ---- output
   if (OUT == OUT_LN) {  // LayerNorm(elementwise_affine=False), eps 1e-5  (ops/basic.py:18)
+    // single-round launches: the residual rows are requested BEFORE the LayerNorm arithmetic (`act` and `x2t` are dead by
+    // now) instead of one exposed round trip each after it; the additions below are the same, in the same order
+    constexpr bool EARLY = LONE && !BF && NB == 8;
+    if constexpr (EARLY) {
+      if (a.resid) load_rows<NB>(act, a.resid + row * D, lg);
+      if constexpr (KEEP2) { if (a.resid2) load_rows<NB>(x2t, a.resid2 + row * D, lg); }
+    }
     const float mean = row_sum<NB>(acc) * (1.f / D);
     float ss = 0.f;
 #pragma unroll
@@ -839,14 +888,19 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     store_rows<NB, false>(acc, a.yln, roff, lg);
     if (a.rstd && lg == 0) a.rstd[row] = rstd;
     if (a.resid) {
-      load_rows<NB>(act, a.resid + row * D, lg);
+      if constexpr (!EARLY) load_rows<NB>(act, a.resid + row * D, lg);
 #pragma unroll
       for (int t = 0; t < NB; ++t) acc[t] += act[t];
     }
     if (a.resid2) {   // (LN + x) + skip: the same two additions, in the same order, as GMP's `+ x` then BSGMP's `h + down_outs`
-      load_rows<NB>(act, a.resid2 + row * D, lg);
+      if constexpr (EARLY && KEEP2) {
 #pragma unroll
-      for (int t = 0; t < NB; ++t) acc[t] += act[t];
+        for (int t = 0; t < NB; ++t) acc[t] += x2t[t];
+      } else {
+        load_rows<NB>(act, a.resid2 + row * D, lg);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) acc[t] += act[t];
+      }
     }
     store_rows<NB, false>(acc, a.y, roff, lg, a.out_mode);
     if (TIMING && a.timing && tid == 0) {
@@ -1665,6 +1719,17 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
       launched = true;
     }
   }
+#ifdef BSMS_EXPERIMENTS
+  if constexpr (NB == 8 && IN == IN_ROWS2 && OUT == OUT_LN) {   // experiments: phase stamps of a single-round node chain (profiles/lone_timeline.py)
+    if (a.timing && a.ntiles <= device_cus()) {
+      static const hipError_t tattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, true, false, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      BSMS_REQUIRE(tattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (timing build)");
+      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, true, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
+      launched = true;
+    }
+  }
+#endif
   if constexpr ((NB == 8 || NB == 16) && IN == IN_EDGE && OUT == OUT_LN) {   // the bf16 precision exists for the edge MLP only
     if (a.bf16 && !launched) {
       static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, true>),

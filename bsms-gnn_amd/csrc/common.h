@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 
 #include "../../include/bsms_hip.h"
 
@@ -96,6 +97,18 @@ struct bsms_plan {
   int32_t *rowptr = nullptr, *src = nullptr, *dst = nullptr, *perm = nullptr;
   int32_t *t_rowptr = nullptr, *t_dst = nullptr, *t_eid = nullptr, *t_pos = nullptr;
   int32_t *ids = nullptr, *inv = nullptr;
+  // pooled transitions, compacted (built by bsms_plan_set_pool; plan.hip).  restrict: CSR over the KEPT rows only,
+  //   k_rowptr[Nk+1]; k_src[q] fine source node; k_eid[q] caller's edge id -- the slots of kept row ids[k] in plan order.
+  // prolong: CSR over ALL fine rows by source with the slots whose target is not kept dropped (they add nothing),
+  //   p_rowptr[N+1]; p_src[t] COARSE row of the target (inv[t_dst]); p_eid[t] caller's edge id.
+  // k_w / p_w: the edge weights in those slot orders, filled by bsms_plan_bind_edge_weights (w_bound = the `ew` they were
+  // gathered from): a transition kernel then reads index + weight as two coalesced streams instead of chasing
+  // rows -> rowptr -> (xidx, widx) -> (xmap, w) through four dependent round trips.
+  int32_t *k_rowptr = nullptr, *k_src = nullptr, *k_eid = nullptr, *p_rowptr = nullptr, *p_src = nullptr, *p_eid = nullptr;
+  float *k_w = nullptr, *p_w = nullptr;
+  int64_t Ek = 0, Ep = 0;
+  const float* w_bound = nullptr;
+  std::vector<int32_t> host;                         // host copy of the index block (set_pool derives the compact lists from it)
   int32_t *block = nullptr, *pool_block = nullptr;   // the two device allocations the pointers above point into
   size_t block_cap = 0, pool_cap = 0;                // their capacities in bytes (plan.hip recycles them)
   int device = 0;                                    // the device the blocks live on (current device at bsms_plan_create)

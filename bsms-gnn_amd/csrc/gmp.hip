@@ -262,7 +262,7 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     }
     a.y = sv.e_y; a.rstd = sv.e_rstd;
     if (training && !bf) for (int st = 0; st < H; ++st) a.amax[st] = sv.bound + size_t(st) * kBoundWidth;
-    a.timing = g_timing;
+    a.timing = (g_debug_flags & 512) ? nullptr : g_timing;   // experiments: bit 9 hands the stamp buffer to the node chain instead
     a.store_mode = ((g_debug_flags & 2) ? 0 : 1) | ((g_debug_flags & 64) ? 4 : 0) | ((g_debug_flags & 128) ? 8 : 0);   // non-temporal stores (experiments: +4 no sign bits, +8 unpaired 64-byte pieces)
     a.out_mode = (g_debug_flags & 4) ? 1 : 0;
     if (g_debug_flags & 1) {
@@ -287,6 +287,7 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x; a.resid2 = resid2;
     if (training) for (int st = 0; st <= H; ++st) a.amax[st] = sv.bound + size_t(8 + st) * kBoundWidth;
     a.store_mode = 1;
+    a.timing = (g_debug_flags & 512) ? g_timing : nullptr;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_LN, a, s))) return rc;
   }
   return BSMS_OK;

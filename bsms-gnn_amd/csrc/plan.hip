@@ -240,6 +240,7 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
     bsms_plan_destroy(p);
     return rc;
   }
+  p->host.swap(blk);   // kept: bsms_plan_set_pool builds the compact transition lists from it
   p->rowptr = p->block;
   p->t_rowptr = p->rowptr + nN;
   p->src = p->t_rowptr + nN;
@@ -256,9 +257,9 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
   BSMS_REQUIRE(p != nullptr, BSMS_E_INVALID_ARG, "plan_set_pool: plan is null");
   BSMS_REQUIRE(Nk >= 0 && Nk <= p->N && (ids != nullptr || Nk == 0), BSMS_E_SHAPE,
                "plan_set_pool: bad Nk=%lld for N=%lld", (long long)Nk, (long long)p->N);
-  const size_t nK = idx_pad(size_t(Nk));
-  std::vector<int32_t> blk(nK + idx_pad(size_t(p->N)), -1);
-  int32_t *h_ids = blk.data(), *h_inv = h_ids + nK;
+  const size_t nK = idx_pad(size_t(Nk)), nNinv = idx_pad(size_t(p->N));
+  std::vector<int32_t> head(nK + nNinv, -1);
+  int32_t *h_ids = head.data(), *h_inv = h_ids + nK;
   for (int64_t k = 0; k < Nk; ++k) {
     BSMS_REQUIRE(ids[k] >= 0 && ids[k] < p->N, BSMS_E_INVALID_ARG, "plan_set_pool: id %lld out of range",
                  (long long)ids[k]);
@@ -266,14 +267,54 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
     h_ids[k] = (int32_t)ids[k];
     h_inv[ids[k]] = (int32_t)k;
   }
+  // compact lists of the two pooled transitions (common.h), from the host copy of the CSR
+  const size_t nN = idx_pad(size_t(p->N) + 1), nE = idx_pad(size_t(p->E));
+  const int32_t *rowptr = p->host.data(), *t_rowptr = rowptr + nN, *src = t_rowptr + nN, *perm = src + 2 * nE,
+                *t_dst = perm + nE, *t_eid = t_dst + nE;
+  int64_t Ek = 0, Ep = 0;
+  for (int64_t k = 0; k < Nk; ++k) Ek += rowptr[h_ids[k] + 1] - rowptr[h_ids[k]];
+  for (int64_t t = 0; t < p->E; ++t) Ep += h_inv[t_dst[t]] >= 0;
+  const size_t nK1 = idx_pad(size_t(Nk) + 1), nEk = idx_pad(size_t(Ek)), nEp = idx_pad(size_t(Ep));
+  std::vector<int32_t> blk(nK + nNinv + nK1 + 2 * nEk + nN + 2 * nEp + nEk + nEp, 0);
+  std::copy(head.begin(), head.end(), blk.begin());
+  int32_t *k_rowptr = blk.data() + nK + nNinv, *k_src = k_rowptr + nK1, *k_eid = k_src + nEk, *p_rowptr = k_eid + nEk,
+          *p_src = p_rowptr + nN, *p_eid = p_src + nEp;
+  {
+    int64_t q = 0;
+    for (int64_t k = 0; k < Nk; ++k) {
+      k_rowptr[k] = (int32_t)q;
+      for (int32_t s = rowptr[h_ids[k]]; s < rowptr[h_ids[k] + 1]; ++s, ++q) { k_src[q] = src[s]; k_eid[q] = perm[s]; }
+    }
+    k_rowptr[Nk] = (int32_t)q;
+    int64_t u = 0;
+    for (int64_t i = 0; i < p->N; ++i) {
+      p_rowptr[i] = (int32_t)u;
+      for (int32_t t = t_rowptr[i]; t < t_rowptr[i + 1]; ++t)
+        if (h_inv[t_dst[t]] >= 0) { p_src[u] = h_inv[t_dst[t]]; p_eid[u] = t_eid[t]; ++u; }
+    }
+    p_rowptr[p->N] = (int32_t)u;
+  }
   release_block(p->pool_block, p->pool_cap, p->device);
   p->pool_block = p->ids = p->inv = nullptr;
-  p->Nk = 0;
+  p->k_rowptr = p->k_src = p->k_eid = p->p_rowptr = p->p_src = p->p_eid = nullptr;
+  p->k_w = p->p_w = nullptr;
+  p->w_bound = nullptr;
+  p->Nk = p->Ek = p->Ep = 0;
   int rc;
   if ((rc = upload_block(&p->pool_block, &p->pool_cap, blk))) return rc;
   p->ids = p->pool_block;
   p->inv = p->pool_block + nK;
+  p->k_rowptr = p->inv + nNinv;
+  p->k_src = p->k_rowptr + nK1;
+  p->k_eid = p->k_src + nEk;
+  p->p_rowptr = p->k_eid + nEk;
+  p->p_src = p->p_rowptr + nN;
+  p->p_eid = p->p_src + nEp;
+  p->k_w = reinterpret_cast<float*>(p->p_eid + nEp);
+  p->p_w = p->k_w + nEk;
   p->Nk = Nk;
+  p->Ek = Ek;
+  p->Ep = Ep;
   return BSMS_OK;
 }
 

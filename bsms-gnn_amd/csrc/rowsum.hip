@@ -584,6 +584,30 @@ extern "C" int bsms_cal_ew(const bsms_plan_t* p, const float* w, float* ec, floa
   return BSMS_OK;
 }
 
+// (lives here, not in plan.hip: that file is host-only C++ -- the sanitizer build compiles it with g++)
+namespace {
+__global__ __launch_bounds__(256) void k_bind_ew(const float* ew, const int32_t* k_eid, float* k_w, int32_t Ek, const int32_t* p_eid,
+                                                 float* p_w, int32_t Ep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < Ek) k_w[i] = ew[k_eid[i]];
+  if (i < Ep) p_w[i] = ew[p_eid[i]];
+}
+}  // namespace
+
+extern "C" int bsms_plan_bind_edge_weights(bsms_plan_t* p, const float* ew, bsms_stream_t stream) {
+  BSMS_REQUIRE(p != nullptr, BSMS_E_INVALID_ARG, "plan_bind_edge_weights: plan is null");
+  if (!ew) { p->w_bound = nullptr; return BSMS_OK; }
+  BSMS_REQUIRE(p->ids != nullptr, BSMS_E_INVALID_ARG, "plan_bind_edge_weights: the plan has no pool (bsms_plan_set_pool)");
+  const int64_t n = std::max(p->Ek, p->Ep);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_bind_ew, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), ew, p->k_eid, p->k_w,
+                       (int32_t)p->Ek, p->p_eid, p->p_w, (int32_t)p->Ep);
+    BSMS_LAUNCH_CHECK();
+  }
+  p->w_bound = ew;
+  return BSMS_OK;
+}
+
 extern "C" int bsms_edge_conv(const bsms_plan_t* p, const float* x, int64_t B, int64_t D, const float* ew,
                               int aggregating, int pooled, float* out, bsms_stream_t stream) {
   return bsms::edge_conv_add(p, x, B, D, ew, aggregating, pooled, out, nullptr, as_stream(stream));
@@ -599,6 +623,22 @@ int bsms::edge_conv_add(const bsms_plan* p, const float* x, int64_t B, int64_t D
   RowSumArgs a{};
   a.w = ew; a.x = x; a.out = out;
   a.B = (int32_t)B; a.D = (int32_t)D;
+  if (pooled && ew == p->w_bound && p->w_bound) {
+    // the mesh-static pooled transitions with BOUND weights (bsms_plan_bind_edge_weights): compact CSR + weights in slot
+    // order (common.h) -- per output row one rowptr pair, then index and weight as two coalesced streams, then the rows:
+    // two dependent round trips fewer than rows -> rowptr -> (xidx, widx) -> (xmap, w).  Same additions in the same order
+    // (the dropped slots of the prolongation were skipped by a select before): bit-identical.
+    a.addend = addend;
+    if (aggregating) {
+      a.rowptr = p->k_rowptr; a.xidx = p->k_src; a.w = p->k_w;
+      a.n_out = (int32_t)p->Nk; a.x_bstride = p->N * D;
+    } else {
+      a.rowptr = p->p_rowptr; a.xidx = p->p_src; a.w = p->p_w;
+      a.n_out = (int32_t)p->N; a.x_bstride = p->Nk * D;
+    }
+    a.out_bstride = int64_t(a.n_out) * D;
+    return launch_rowsum(a, stream);
+  }
   if (aggregating) {            // by target: fine x -> all rows or kept rows
     a.rowptr = p->rowptr; a.xidx = p->src; a.widx = p->perm;
     a.rows = pooled ? p->ids : nullptr;

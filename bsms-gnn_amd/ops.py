@@ -13,12 +13,11 @@ call sites carry over unchanged:
 
 PyTorch is used for device memory, streams and autograd glue only; every tensor op of the path is a
 call through the C ABI.  There is no CPU fallback: CPU tensors raise."""
+import os
 from typing import Optional
 
 import torch
 from torch import nn
-
-import os
 
 from . import _abi
 from .graph import LevelPlan, plan_for, plans_for
@@ -633,6 +632,11 @@ class BSGMP(nn.Module):
                 ew, w_full = self.edge_conv.cal_ew(w, None, plan=plan)
                 w = w_full[ids]
                 ews.append(ew)
+                # the weights are mesh-static and cached with the plan: gather them once into the slot orders of the pooled
+                # transitions (restrict / prolong then read compact index + weight streams, csrc/rowsum.hip)
+                if os.environ.get("BSMS_BIND_EW", "1") == "1":     # ("0": same-box A/B of the unbound index-chasing path, profiles/ab_env.sh)
+                    _abi.check(_abi.lib().bsms_plan_bind_edge_weights(plan.handle, ew.data_ptr(), _stream()), "bsms_plan_bind_edge_weights")
+                    plan._ew_bound = ew        # the binding is by ADDRESS: the plan keeps the tensor alive, so the address cannot be recycled while bound
             plans[0]._ew_chain = (key, ews)                      # keyed by plan uids: no reference cycle through the plans
         return ews
 

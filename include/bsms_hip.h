@@ -85,6 +85,13 @@ const char* bsms_last_error(void);
  * still in flight, as for any buffer it owns.  bsms_plan_pool_trim releases the pooled blocks (waits for the device). */
 int bsms_plan_create(const int64_t* coo_host, int64_t E, int64_t N, bsms_plan_t** out);
 int bsms_plan_set_pool(bsms_plan_t* plan, const int64_t* ids_host, int64_t Nk);
+/* Binds the DEVICE edge weights `ew` [E] (edge order; WeightedEdgeConv.cal_ew, ops/basic.py:142-167 -- mesh-static, the
+ * reference recomputes them every forward, BSMS.py:73) to a plan with a pool: they are gathered once into the slot orders
+ * of the two pooled transitions, and every later bsms_edge_conv(..., ew, ..., pooled = 1) / U-Net call that passes the
+ * SAME pointer takes compact index + weight streams instead of four levels of dependent index loads.  The caller
+ * guarantees that the content of `ew` is unchanged for as long as it passes that pointer; ew = NULL unbinds.  Results
+ * are bit-identical to the unbound path.  A new bsms_plan_set_pool unbinds. */
+int bsms_plan_bind_edge_weights(bsms_plan_t* plan, const float* ew, bsms_stream_t stream);
 int bsms_plan_destroy(bsms_plan_t* plan);
 int bsms_plan_pool_trim(void);
 int64_t bsms_plan_num_nodes(const bsms_plan_t* plan);

@@ -2,7 +2,7 @@
 """HBM bytes per launch of the L0 aggregation kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of
 `python bench.py --roofline-only`, corrected as MI355X_MICROARCH.md prescribes (unit KiB; gfx950 reports half of a
 wide 16 B/lane read).  Writes profiles/aggregation_traffic.json and a compact per-dispatch CSV.
-  python profiles/pmc_traffic.py <fetch>_counter_collection.csv <write>_counter_collection.csv <kernel_stats.csv>"""
+  python profiles/pmc_traffic.py <fetch>_counter_collection.csv <write>_counter_collection.csv <kernel_stats.csv> [tag = r01]"""
 import csv, json, os, sys
 KERNEL = "k_rowsum_v4<32, false, false, false>"
 def collect(path, counter):
@@ -28,7 +28,10 @@ out = {"kernel": KERNEL.replace(", ", ",") + " at airfoil L0 (B=8, E=31354, N=52
        "rocprof_avg_duration_us": avg_us, "launches": len(fetch)}
 here = os.path.dirname(os.path.abspath(__file__))
 json.dump(out, open(os.path.join(here, "aggregation_traffic.json"), "w"), indent=1)
-with open(os.path.join(here, "r01_aggregation_pmc.csv"), "w") as fh:
+tag = sys.argv[4] if len(sys.argv) > 4 else "r01"
+out["taken"] = tag
+json.dump(out, open(os.path.join(here, "aggregation_traffic.json"), "w"), indent=1)
+with open(os.path.join(here, f"{tag}_aggregation_pmc.csv"), "w") as fh:
     fh.write("Dispatch_Id,Kernel_Name,Grid_Size,Counter_Name,Counter_Value\n")
     for row in rf[:20] + rw[:20]:
         fh.write(",".join(f'"{x}"' if "," in x else x for x in row) + "\n")

@@ -193,6 +193,60 @@ def test_transition_gradients_and_adjoint(eng, graphs):
     assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
 
 
+@pytest.mark.parametrize("name", ["del64", "del300", "surf200"])
+def test_bound_edge_weights_transitions_bit_identical(eng, graphs, name):
+    """bsms_plan_bind_edge_weights: the pooled transitions with weights gathered once into compact slot order (kept-row CSR
+    for restrict, by-source CSR without the dropped targets for prolong) perform the same additions in the same order as
+    the index-chasing path -- restrict, prolong and both adjoint shapes, features (D = 128, 32) and positions (D = 2, 3:
+    scalar kernel), with a fused addend; a NEW weight tensor or a re-pooled plan falls back / rebinds correctly."""
+    from bsms_gnn_amd import _abi
+    from bsms_gnn_amd.ops import _stream
+    es, ids = graphs.levels(name)
+    n0, nk = graphs.np(f"{name}/pos").shape[0], ids[0].numel()
+    L = _abi.lib()
+    plan = eng.LevelPlan(dev(es[0]), n0, ids=dev(ids[0]))
+    ew = dev(ro.cal_ew(torch.ones(n0, 1), es[0])[0])
+    torch.manual_seed(7)
+
+    def run(w, D, B=2):
+        fine, coarse = torch.randn(B, n0, D, device="cuda"), torch.randn(B, nk, D, device="cuda")
+        out = []
+        for agg, x, n_out in ((1, fine, nk), (0, coarse, n0)):
+            y = torch.empty(B, n_out, D, device="cuda")
+            _abi.check(L.bsms_edge_conv(plan.handle, x.data_ptr(), B, D, w.data_ptr(), agg, 1, y.data_ptr(), _stream()), "edge_conv")
+            out.append(y)
+        return fine, coarse, out
+
+    for D in (128, 32, 2, 3):
+        torch.manual_seed(D)
+        _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, None, _stream()), "unbind")
+        _, _, slow = run(ew, D)
+        torch.manual_seed(D)
+        _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, ew.data_ptr(), _stream()), "bind")
+        _, _, fast = run(ew, D)
+        assert torch.equal(slow[0], fast[0]) and torch.equal(slow[1], fast[1]), D
+        other = ew * 0.5                                   # another tensor: not the bound pointer -> generic path, its own values
+        torch.manual_seed(D)
+        _, _, half = run(other, D)
+        torch.manual_seed(D)
+        _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, other.data_ptr(), _stream()), "rebind")
+        _, _, half_fast = run(other, D)
+        assert torch.equal(half[0], half_fast[0]) and torch.equal(half[1], half_fast[1]), D
+    # the whole U-Net with bound weights (BSGMP.prepare binds them) == the golden output is covered by test_bsgmp_golden;
+    # re-pooling unbinds: results follow the new pool
+    keep = ids[0][: max(2, nk // 2)]
+    plan.set_pool(dev(keep))
+    x = torch.randn(1, n0, 32, device="cuda")
+    y = torch.empty(1, keep.numel(), 32, device="cuda")
+    _abi.check(L.bsms_edge_conv(plan.handle, x.data_ptr(), 1, 32, ew.data_ptr(), 1, 1, y.data_ptr(), _stream()), "edge_conv")
+    want = ro.edge_conv(x.cpu(), es[0], ew.cpu())[:, keep]
+    assert torch.equal(y.cpu(), want)
+    _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, ew.data_ptr(), _stream()), "bind")
+    y2 = torch.empty_like(y)
+    _abi.check(L.bsms_edge_conv(plan.handle, x.data_ptr(), 1, 32, ew.data_ptr(), 1, 1, y2.data_ptr(), _stream()), "edge_conv")
+    assert torch.equal(y2.cpu(), want)
+
+
 def test_cal_ew_degree_quirk(eng):
     """degree() has length max(g[0])+1: a trailing node without out-edges breaks w/deg."""
     g = torch.tensor([[0, 1], [1, 2]])  # node 2 never sends
