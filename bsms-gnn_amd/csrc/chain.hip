@@ -1,6 +1,14 @@
 // Chain kernels (see chain.h for the register-layout idea) + weight prepack.
 #include "chain.h"
 
+// No implicit contraction in this file: hipcc defaults to -ffp-contract=fast and decides PER INSTANTIATION whether a
+// multiply feeding an add becomes one fma -- the LayerNorm backward `g - m1 - y * m2` came out fused in some kernel
+// variants and not in others, so the input gradient of a row depended (in the last bit) on the launch shape that
+// happened to process it (found by tests/test_hip_parity.py::test_feature_split_kernels_equal_the_ring_kernels).
+// Every fused multiply-add of the arithmetic is written as fmaf() explicitly; with this pragma nothing else is fused and
+// all variants of a kernel (ring / single-round / pipelined edge / feature-split) agree bit for bit.
+#pragma clang fp contract(off)
+
 using namespace bsms;
 
 namespace {
@@ -560,6 +568,73 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
 #endif
   int fw = 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (LONE && NB == 8) {
+    // ---- single-round launches: one wave per SIMD, nothing hides its stalls.  Measured per stage of the node MLP at the
+    // coarse levels (profiles/lone_timeline.py): 750 cycles per chunk for 24 MFMAs (408 back to back) = the chunk barrier
+    // (~100) + the LDS round trip of the first fragments (~250: reads of a chunk cannot be issued before its barrier) +
+    // the MFMAs.  So the chunks are software-pipelined: the wave passes the barrier of chunk c + 1 and requests its
+    // fragments BEFORE the last MFMAs of chunk c, which run from registers -- the round trip is exposed once per stage
+    // instead of once per chunk.  Barrier count and order are
+    // unchanged (one per chunk), and the loader's ring protocol holds: after barrier c + 1 it may overwrite the slot of
+    // chunk c, of which this wave has nothing left to read (its fragments are in registers; only the LAST chunk's header
+    // -- the bias -- is read after its MFMAs, and the barrier after the last chunk belongs to the next stage).
+    // The three products of an accumulator keep their order (h_w l_x, h_w h_x, l_w h_x): bit-identical results.
+    // Rolling half-chunk window, 64 fragment registers: feature blocks 0-3 of a chunk ("g0") and 4-7 ("g1") each have
+    // one register set; g1 of chunk c is requested before the MFMAs of g0, then the barrier of chunk c + 1 is passed and
+    // ITS g0 requested into the registers g0 of chunk c has just freed, under the MFMAs of g1.
+    float4 g0[NB], g1[NB];          // [2 * k + plane] for feature block k (g0) / 4 + k (g1)
+    const float4* hdr_last = nullptr;
+    const float4* body = nullptr;
+    auto pass_barrier = [&]() {
+      if (TIMED) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        lds_barrier();
+        *waited += __builtin_amdgcn_s_memtime() - t0;
+      } else {
+        lds_barrier();
+      }
+    };
+    auto next_chunk = [&]() {        // the ring's next chunk becomes the current one; its first half is requested
+      hdr_last = lds + slot.i * R::CH4;
+      if (++slot.i == slot.nr) slot.i = 0;
+      body = hdr_last + kChunkHdrFloats / 4 + lane;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) g0[k] = body[k * 64];
+    };
+    pass_barrier();
+    next_chunk();
+    fw = int(__float_as_uint(reinterpret_cast<const float*>(hdr_last)[kScaleSlot]) >> 23);
+#pragma unroll
+    for (int c = 0; c < R::NCH; ++c) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) g1[k] = body[(NB + k) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      if (paired) store_pair_stream<NB>(act, store_base, row, nrows, lane, 2 * c, streaming);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = mma(g0[2 * k], bl[c], (ZERO && c == 0) ? zero : acc[k]);
+      // VALU work for later, placed among this chunk's MFMAs
+      if (c + 1 < R::NCH) split_block<NB>(act, c + 1, rs.s, bh[c + 1], bl[c + 1]);
+      else if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = mma(g0[2 * k], bh[c], acc[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = mma(g0[2 * k + 1], bh[c], acc[k]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < R::NCH) {
+        pass_barrier();               // chunk c + 1 has landed (its lgkmcnt(0): g1 of chunk c is in registers from here on)
+        next_chunk();                 // g0 <- first half of chunk c + 1 (the registers the MFMAs above have released)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[4 + k] = mma(g1[2 * k], bl[c], (ZERO && c == 0) ? zero : acc[4 + k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[4 + k] = mma(g1[2 * k], bh[c], acc[4 + k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[4 + k] = mma(g1[2 * k + 1], bh[c], acc[4 + k]);
+    }
+    if (FIN != 0) finish_stage<NB, FIN == 2>(acc, rs.E, fw, reinterpret_cast<const float*>(hdr_last), lane);
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < R::NCH; ++c) {
     if (TIMED) {   // experiments: cycles this wave spends waiting at the chunk barriers
@@ -575,36 +650,8 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
     if (paired) store_pair_stream<NB>(act, store_base, row, nrows, lane, 2 * c, streaming);
     const float4* body = cur + kChunkHdrFloats / 4 + lane;
     // Two accumulators interleaved so that back-to-back MFMAs are independent.
-    if constexpr (LONE && NB == 8) {
-      // A launch of one round of workgroups has a single wave per SIMD: nothing hides its stalls.  Measured per stage of
-      // the node MLP at the coarse levels (profiles/lone_timeline.py): 3.0k cycles for the 96 MFMAs of a stage (31 each,
-      // against 17 back to back) with fragments read ONE pair ahead -- an LDS round trip (~200 cycles for a lone wave)
-      // is longer than the four MFMAs that were supposed to cover it -- and with only two accumulator chains in flight.
-      // Here the 2 NB fragments of the chunk are requested at once (64 VGPRs of the 256-register budget; the MFMAs
-      // consume them in request order behind counted lgkmcnt waits) and four accumulator chains interleave.  The three
-      // products of an accumulator keep their order (h_w l_x, h_w h_x, l_w h_x): bit-identical results.
-      float4 fh[NB], fl[NB];
-#pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        fh[t] = body[(t * 2) * 64];
-        fl[t] = body[(t * 2 + 1) * 64];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < NB; t += 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[t + k] = mma(fh[t + k], bl[c], (ZERO && c == 0) ? zero : acc[t + k]);
-        if (t == 0) {   // VALU work for later, placed among this chunk's MFMAs
-          if (c + 1 < R::NCH) split_block<NB>(act, c + 1, rs.s, bh[c + 1], bl[c + 1]);
-          else if (mask_rows) store_mask_bits<NB>(act, store_base, mask_rows, store_off, lane >> 4);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[t + k] = mma(fh[t + k], bh[c], acc[t + k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[t + k] = mma(fl[t + k], bh[c], acc[t + k]);
-      }
-    } else if constexpr (LONE) {
-      // (D = 256: the fragments of a whole chunk do not fit next to 64 + 64 activation / accumulator registers)
+    if constexpr (LONE) {
+      // (D = 256; D = 128 takes the pipelined path above: the fragments of whole chunks do not fit next to 64 + 64 activation / accumulator registers)
       // pairs are read ONE PAIR AHEAD (f = current, n = next), pinned by sched_barrier.
       float4 f0 = body[0], f1 = body[2 * 64];                                      // (t = 0, plane h)
 #pragma unroll
@@ -918,6 +965,304 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   }
   }  // tile loop
   flush_bounds(a.amax, kMaxStages + 1, brow, wave, lane);
+}
+
+// ------------------------------------------------------------------- small launches: feature-split forward chain ----
+// A launch of a few thousand rows at most (every node-level MLP of a batch-1 step / rollout, the coarse levels of any
+// step) is LATENCY, not throughput: in k_chain_fwd one wave per SIMD owns 16 rows x all 128 features and works through
+// ~750-900 cycles per 32-feature chunk (profiles/census/stage_lone.hip: 24 MFMAs 427, its 16 ds_read_b128 of shared
+// weight fragments 513 at the rate a lone wave gets, the two-way split 187, barrier-serialised), 4.5k cycles per Linear,
+// 12 us for the node MLP whatever the row count -- and no loader / ring variation moves it (profiles/lone_timeline.py).
+// Here the FEATURES of a 16-row tile are split over the four waves of a 256-thread workgroup: wave w owns output feature
+// blocks 2w, 2w+1 of every Linear = a quarter of the MFMAs, of the split, of the epilogue arithmetic.  Its accumulator
+// layout is exactly K block w of the next Linear's B operand (chain.h), so what the waves exchange through LDS per
+// Linear is 2 KB of fp16 pieces each plus the row maximum -- two LDS barriers.  Each wave needs only ITS quarter of every
+// weight chunk, and all four together read each weight byte once per tile: the fragments come straight from L2 into
+// registers (one 1 KB global_load_dwordx4 per fragment), a whole Linear ahead -- no LDS ring, no loader wave, no chunk
+// barriers.  Per-element arithmetic and its order are those of k_chain_fwd (same split, same three products per
+// accumulator in the same order, same row scale, LayerNorm on the full row gathered through LDS): BIT-IDENTICAL results
+// (tests/test_hip_parity.py::test_feature_split_kernels_equal_the_ring_kernels).  Weight traffic per row is 4-14x that
+// of the persistent ring kernels, so the launcher takes this path only below kFsMaxRows rows.
+constexpr int kFsMaxRows = 12288;   // 768 tiles of 16 rows: three per CU
+
+struct FsPack {           // one weight pack of the chain as wave `w` sees it
+  float4 f[16];           // [chunk c][block i = 0, 1][plane h, l]  -> f[c * 4 + i * 2 + plane]
+  float4 bias[2];         // bias of the own feature blocks (header of the last chunk), this lane's features
+  float scale;            // 2^-k_w (header float kScaleSlot of chunk 0)
+};
+__device__ __forceinline__ void fs_request(FsPack& p, const float4* wp, int w, int lane) {
+  using R = Ring<8>;
+  const float4* body = wp + kChunkHdrFloats / 4 + lane;
+#pragma unroll
+  for (int c = 0; c < R::NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) p.f[c * 4 + i * 2 + pl] = body[size_t(c) * R::CH4 + ((2 * w + i) * 2 + pl) * 64];
+  const float* hdr_last = reinterpret_cast<const float*>(wp + size_t(R::NCH - 1) * R::CH4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) p.bias[i] = *reinterpret_cast<const float4*>(hdr_last + 16 * (2 * w + i) + 4 * (lane >> 4));
+  p.scale = reinterpret_cast<const float*>(wp)[kScaleSlot];
+}
+
+// the four K blocks of the activation entering a Linear, as B operands
+struct FsPieces { u32x4 h[4], l[4]; };
+
+// One Linear on the own feature blocks.  ZERO / FIN as in mfma_stage.
+template <bool ZERO, int FIN>
+__device__ __forceinline__ void fs_stage(f32x4 (&acc)[2], const FsPack& p, const FsPieces& x, int E, int lane) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = mma(p.f[c * 4 + i * 2], x.l[c], (ZERO && c == 0) ? zero : acc[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = mma(p.f[c * 4 + i * 2], x.h[c], acc[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = mma(p.f[c * 4 + i * 2 + 1], x.h[c], acc[i]);
+  }
+  if (FIN != 0) {   // finish_stage on the own blocks: same fast / slow path decision (wave-uniform over the same 16 rows)
+    const int fw = int(__float_as_uint(p.scale) >> 23);
+    const int f = E + fw - 139;
+    if (__builtin_amdgcn_ballot_w64(unsigned(f - 1) >= 254u) == 0) {
+      const float inv = __uint_as_float(unsigned(f) << 23);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (FIN == 2) acc[i] = f32x4{fmaf(acc[i][0], inv, p.bias[i].x), fmaf(acc[i][1], inv, p.bias[i].y), fmaf(acc[i][2], inv, p.bias[i].z), fmaf(acc[i][3], inv, p.bias[i].w)};
+        else acc[i] *= inv;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 b = FIN == 2 ? p.bias[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[i] = f32x4{ldexpf(acc[i][0], f - 127) + b.x, ldexpf(acc[i][1], f - 127) + b.y, ldexpf(acc[i][2], f - 127) + b.z, ldexpf(acc[i][3], f - 127) + b.w};
+      }
+    }
+  }
+}
+
+struct FsLds {
+  float pmax[16][16];       // [row][4 w + g]: largest |value| of the row among the features held by (wave w, lane group g)
+  u32x4 piece[4][2][64];    // [K block][plane][lane]
+  float zrow[16][132];      // full rows for the LayerNorm / the narrow output layer (pitch 132: 16-byte aligned, spread over banks)
+};
+
+__device__ __forceinline__ float fs_amax2(const f32x4 (&v)[2]) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    m = fmaxf(fmaxf(m, fabsf(v[i][0])), fabsf(v[i][1]));
+    m = fmaxf(fmaxf(m, fabsf(v[i][2])), fabsf(v[i][3]));
+  }
+  return m;
+}
+// row maximum over all 128 features: every (wave, lane group) publishes its part, everybody reads the 16 parts of its row
+__device__ __forceinline__ float fs_row_max(FsLds& L, float mloc, int w, int lane) {
+  L.pmax[lane & 15][4 * w + (lane >> 4)] = mloc;
+  lds_barrier();
+  const float4* p = reinterpret_cast<const float4*>(L.pmax[lane & 15]);
+  const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+  return fmaxf(fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))),
+               fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w))));
+}
+// own K block -> fp16 pieces, published; the other three are read back
+__device__ __forceinline__ void fs_publish(FsLds& L, FsPieces& x, const f32x4 (&own)[2], float s, int w, int lane) {
+  u32x4 h, l;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    unsigned hh, ll;
+    split_h2(own[v >> 1][2 * (v & 1)], own[v >> 1][2 * (v & 1) + 1], s, hh, ll);
+    h[v] = hh;
+    l[v] = ll;
+  }
+  L.piece[w][0][lane] = h;
+  L.piece[w][1][lane] = l;
+  lds_barrier();
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    x.h[kb] = L.piece[kb][0][lane];
+    x.l[kb] = L.piece[kb][1][lane];
+  }
+}
+// largest |value| over the tile's rows -> this workgroup's entry of a bound slot (chain.h; wave 0 only: m is per row)
+__device__ __forceinline__ void fs_note(float* slot, float m, int w, int lane) {
+  if (!slot || w != 0) return;   // uniform
+  int v = __float_as_int(m);
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));
+  if (lane == 15) slot[int(blockIdx.x) * 8] = __int_as_float(v);
+}
+// saved activation (values + ReLU sign bits) of the own feature blocks, act_floats layout (chain.h)
+__device__ __forceinline__ void fs_save(float* base, const f32x4 (&own)[2], int64_t R, int64_t row, bool live, int w, int lane, bool bits) {
+  if (!base || !live) return;
+  constexpr int D = 128;
+  const int lg = lane >> 4;
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    __builtin_nontemporal_store(own[i], reinterpret_cast<f32x4*>(base + row * D + 16 * (2 * w + i) + 4 * lg));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m |= (__float_as_uint(own[i][r]) != 0u ? 1u : 0u) << (4 * i + r);   // post-ReLU value: positive iff non-zero bits
+  }
+  if (bits) reinterpret_cast<unsigned char*>(base + pad_rows(R) * D)[(row * 4 + lg) * 4 + w] = (unsigned char)m;   // bits 8w .. 8w+7 of the word of (row, group)
+}
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(256) void k_fs_fwd(ChainFwdArgs a) {
+  constexpr int NB = 8, D = 128;
+  __shared__ FsLds L;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lg = lane >> 4;
+  const int64_t row = int64_t(blockIdx.x) * 16 + (lane & 15);
+  const bool live = row < a.R;
+  const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
+  FsPack pa, pb;                         // packs alternate between the two register sets, one Linear ahead
+  fs_request(pa, a.wseq[0], w, lane);
+  f32x4 own[2], acc[2];
+  FsPieces x;
+  float m;
+  // ---- input stage (own feature blocks 2w, 2w+1 = K block w of the first Linear)
+  f32x4 own2[2];
+  if (IN == IN_ROWS || IN == IN_ROWS2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) own[i] = *reinterpret_cast<const f32x4*>(a.x + rowc * D + 16 * (2 * w + i) + 4 * lg);
+    if (IN == IN_ROWS2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) own2[i] = *reinterpret_cast<const f32x4*>(a.x2 + rowc * D + 16 * (2 * w + i) + 4 * lg);
+    }
+  } else {  // IN_SMALL: the narrow first layer on the VALU, relu(b0 + sum_k x[k] W0[:, k])
+#pragma unroll
+    for (int i = 0; i < 2; ++i) own[i] = *reinterpret_cast<const f32x4*>(a.bias_in + 16 * (2 * w + i) + 4 * lg);
+    for (int k = 0; k < a.K0; ++k) {
+      const float xv = a.x[rowc * a.K0 + k];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 wv = *reinterpret_cast<const float4*>(a.w0t + k * D + 16 * (2 * w + i) + 4 * lg);
+        own[i][0] = fmaf(xv, wv.x, own[i][0]);
+        own[i][1] = fmaf(xv, wv.y, own[i][1]);
+        own[i][2] = fmaf(xv, wv.z, own[i][2]);
+        own[i][3] = fmaf(xv, wv.w, own[i][3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) own[i][r] = fmaxf(own[i][r], 0.f);
+    fs_save(a.store_in, own, a.R, row, live, w, lane, !(a.store_mode & 4));
+    if (a.nstage == 0) return;
+  }
+  float mloc = fs_amax2(own);
+  if (IN == IN_ROWS2) mloc = fmaxf(mloc, fs_amax2(own2));
+  m = fs_row_max(L, mloc, w, lane);
+  fs_note(a.amax[0], m, w, lane);
+  RowScale rs = scale_of(m);
+  fs_publish(L, x, own, rs.s, w, lane);
+
+  // ---- Linears.  `q` walks the pack sequence (a.wseq: IN_ROWS2 has two packs for its first Linear, OUT_PLAIN2 one per head)
+  auto run = [&](FsPack& cur, FsPack& nxt, int q, int l) -> bool {   // returns false when the chain is finished
+    if (q + 1 < a.nseq) fs_request(nxt, a.wseq[q + 1], w, lane);
+    if (OUT == OUT_PLAIN2) {   // two Linears of the SAME rows: stage q -> y (q = 0) / y2 (q = 1)
+      fs_stage<true, 2>(acc, cur, x, rs.E, lane);
+      float* y = q == 0 ? a.y : a.y2;
+      if (live)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(y + row * D + 16 * (2 * w + i) + 4 * lg) = acc[i];
+      return q + 1 < a.nseq;
+    }
+    if (IN == IN_ROWS2 && q == 0) {   // first half of the Linear over [x, x2]: raw sums, continued by the second pack
+      fs_stage<true, 0>(acc, cur, x, rs.E, lane);
+      lds_barrier();                  // everybody has read the pieces of x
+      fs_publish(L, x, own2, rs.s, w, lane);
+      return true;
+    }
+    if (IN == IN_ROWS2 && q == 1) fs_stage<false, 2>(acc, cur, x, rs.E, lane);
+    else fs_stage<true, 2>(acc, cur, x, rs.E, lane);
+    const bool last = l == a.nstage - 1;
+    if (!last || OUT == OUT_SMALL) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) own[i][r] = fmaxf(acc[i][r], 0.f);
+    }
+    if (last) return false;
+    fs_save(a.store[l], own, a.R, row, live, w, lane, !(a.store_mode & 4));
+    lds_barrier();                    // the pieces of the previous activation have been read by everybody
+    m = fs_row_max(L, fs_amax2(own), w, lane);
+    fs_note(a.amax[l + 1], m, w, lane);
+    rs = scale_of(m);
+    fs_publish(L, x, own, rs.s, w, lane);
+    return true;
+  };
+  {
+    int q = 0, l = 0;
+    for (;;) {
+      if (!run(pa, pb, q, l)) break;
+      if (!(IN == IN_ROWS2 && q == 0) && OUT != OUT_PLAIN2) ++l;
+      ++q;
+      if (!run(pb, pa, q, l)) break;
+      if (!(IN == IN_ROWS2 && q == 0) && OUT != OUT_PLAIN2) ++l;
+      ++q;
+    }
+  }
+  if (OUT == OUT_PLAIN2) return;
+
+  // ---- output
+  if (OUT == OUT_PLAIN) {
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x4* p = reinterpret_cast<f32x4*>(a.y + row * D + 16 * (2 * w + i) + 4 * lg);
+      f32x4 v = acc[i];
+      if (a.accumulate) v += *p;
+      *p = v;
+    }
+    return;
+  }
+  // OUT_LN / OUT_SMALL work on FULL rows: gather them through LDS in the chain layout, then exactly the arithmetic of k_chain_fwd
+  lds_barrier();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&L.zrow[lane & 15][16 * (2 * w + i) + 4 * lg]) = (OUT == OUT_SMALL) ? own[i] : acc[i];
+  if (OUT == OUT_SMALL && a.store[a.nstage - 1] && live) {   // last hidden activation (plain rows, no sign bits: the backward masks by value)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(a.store[a.nstage - 1] + row * D + 16 * (2 * w + i) + 4 * lg) = own[i];
+  }
+  lds_barrier();
+  f32x4 z[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) z[t] = *reinterpret_cast<const f32x4*>(&L.zrow[lane & 15][16 * t + 4 * lg]);
+  if (!live) return;
+  if (OUT == OUT_LN) {  // LayerNorm(elementwise_affine=False), eps 1e-5  (ops/basic.py:18): every wave normalises the row, stores its quarter
+    const float mean = row_sum<NB>(z) * (1.f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        z[t][r] -= mean;
+        ss = fmaf(z[t][r], z[t][r], ss);
+      }
+    ss = group_sum(ss);
+    const float rstd = 1.f / sqrtf(ss * (1.f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = 2 * w + i;
+      f32x4 v = z[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= rstd;
+      const int64_t o = row * D + 16 * t + 4 * lg;
+      if (a.yln) *reinterpret_cast<f32x4*>(a.yln + o) = v;
+      if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + o);
+      if (a.resid2) v += *reinterpret_cast<const f32x4*>(a.resid2 + o);   // (LN + x) + skip, in this order
+      *reinterpret_cast<f32x4*>(a.y + o) = v;
+    }
+    if (a.rstd && w == 0 && lg == 0) a.rstd[row] = rstd;
+  } else {  // OUT_SMALL: the narrow last Linear (decoder, models/model.py:22) on the VALU; output channel c belongs to wave c % 4
+    for (int c = w; c < a.C; c += 4) {
+      const float v = dot_features<NB>(z, a.wout + c * D, lg);
+      if (lg == 0) a.y[row * a.C + c] = v + a.bout[c];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------- backward chain
@@ -1701,6 +2046,14 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   if constexpr ((NB == 8 || NB == 16) && IN == IN_EDGE && OUT == OUT_LN) {
     int rc = BSMS_OK;
     if (launch_edge_fwd<NB>(a, s, rc)) return rc;
+  }
+  if constexpr (NB == 8 && (IN == IN_ROWS || IN == IN_ROWS2 || IN == IN_SMALL)) {   // small launches: the feature-split kernel
+    static const int fs_rows = knob("BSMS_FS_ROWS", kFsMaxRows);
+    if (!a.bf16 && !a.timing && a.R <= fs_rows && a.nseq >= 1 && a.nseq <= kMaxStages + 1) {
+      hipLaunchKernelGGL((k_fs_fwd<IN, OUT>), dim3((unsigned)ceil_div(a.R, 16)), dim3(256), 0, s, a);
+      BSMS_LAUNCH_CHECK();
+      return BSMS_OK;
+    }
   }
   const int cw = (IN == IN_EDGE) ? knob("BSMS_BFEDGE_CW", kComputeWaves) : chain_compute_waves<NB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);

@@ -450,6 +450,50 @@ def test_weight_gradient_precision_per_column(eng):
               f"(fp32 {float(e_32[small].max()):.2e}); other columns {float(e_mine[big].max()):.2e} (fp32 {float(e_32[big].max()):.2e})")
 
 
+def test_feature_split_kernels_equal_the_ring_kernels(eng):
+    """Launches of at most a few thousand rows take the feature-split chain kernels (csrc/chain.hip: k_fs_fwd: the four waves
+    of a workgroup share a 16-row tile by OUTPUT FEATURES, weights straight from L2), larger ones the persistent ring
+    kernels.  Every row is processed independently with the same arithmetic in the same order, so the first rows of a large
+    launch must equal a small launch of the same rows BIT FOR BIT: forward (training and inference), input gradient; the
+    weight gradients of the two paths agree to round-off.  MLP shapes of the path (encoder, decoder, D -> D with
+    LayerNorm) and a whole GMP block at batch 1 against the same sample inside a batch of 6."""
+    torch.manual_seed(21)
+    D, small, big = 128, 5000, 30000
+    for in_dim, out_dim, ln in ((3, D, True), (D, D, True), (D, 3, False)):
+        mlp = eng.MLP(in_dim, D, out_dim, 3, ln).cuda()
+        x = torch.randn(big, in_dim, device="cuda")
+        with torch.no_grad():
+            y_big, y_small = mlp(x), mlp(x[:small].contiguous())
+        assert torch.equal(y_big[:small], y_small), (in_dim, out_dim)
+        xs = x[:small].clone().requires_grad_(in_dim == D)
+        xb = x.clone().requires_grad_(in_dim == D)
+        ys, yb = mlp(xs), mlp(xb)
+        assert torch.equal(ys.detach(), y_small) and torch.equal(yb.detach()[:small], y_small)     # training forward == inference forward
+    # a GMP block: node-level chains of B = 1 (5000 rows) are feature-split, of B = 6 (30000 rows) ring kernels
+    n, e = 5000, 30000
+    g = random_graph(n, e, 5)
+    gmp = eng.GMP(D, 3, 2).cuda()
+    x6, pos6 = torch.randn(6, n, D, device="cuda"), torch.rand(6, n, 2, device="cuda")
+    with torch.no_grad():
+        y6 = gmp(x6, dev(g), pos6)
+        y1 = gmp(x6[2:3].contiguous(), dev(g), pos6[2:3].contiguous())
+    assert torch.equal(y6[2:3], y1)
+    # training: forward equal, input gradient equal bit for bit (row-independent chains), weight gradients to round-off
+    def step(xx, pp):
+        gmp.zero_grad(set_to_none=True)
+        xx = xx.clone().requires_grad_(True)
+        y = gmp(xx, dev(g), pp)
+        (y * y).sum().backward()
+        return y.detach(), xx.grad, {k: q.grad.clone() for k, q in gmp.named_parameters()}
+    ya, ga, wa = step(x6[2:3].contiguous(), pos6[2:3].contiguous())
+    x_rep, pos_rep = x6[2:3].repeat(6, 1, 1).contiguous(), pos6[2:3].repeat(6, 1, 1).contiguous()
+    yb, gb, wb = step(x_rep, pos_rep)
+    assert torch.equal(ya, y1) and torch.equal(yb[4:5], ya)
+    assert torch.equal(gb[4:5], ga)
+    for k in wa:
+        assert rel_err(wb[k] / 6, wa[k]) < 2e-6, k
+
+
 def test_gmp_magnitude_range_zero_input_and_many_rows(eng):
     """The fp16 x 2 arithmetic scales every activation row, weight matrix and (in the weight gradients) operand tensor by a
     power of two taken from its magnitude (chain.h).  (1) A GMP block whose samples differ by five orders of magnitude and
