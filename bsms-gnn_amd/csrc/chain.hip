@@ -1387,6 +1387,136 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   flush_bounds(a.gmax, kMaxStages + 1, brow, wave, lane);
 }
 
+// ------------------------------------------------------------------ small launches: feature-split backward chain ----
+// k_chain_bwd with the features of a 16-row tile split over four waves (see k_fs_fwd).  The LayerNorm backward needs sums
+// over the whole row in the association of k_chain_bwd (row_sum, then the sequential fmaf chain): every wave reads the full
+// dy / y rows (L2-resident at these sizes) and repeats that arithmetic, then keeps its own feature blocks.  Bit-identical
+// to k_chain_bwd.
+template <int GIN, int FIRST>
+__global__ __launch_bounds__(256) void k_fs_bwd(ChainBwdArgs a) {
+  constexpr int NB = 8, D = 128;
+  __shared__ FsLds L;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lg = lane >> 4;
+  const int64_t row = int64_t(blockIdx.x) * 16 + (lane & 15);
+  const bool live = row < a.R;
+  const int64_t rowc = live ? row : 0;
+  FsPack pa, pb;
+  fs_request(pa, a.wseq[0], w, lane);
+  f32x4 own[2], acc[2];
+  if (GIN == G_SMALL) {  // g = (dy . W_out) masked by the last hidden activation
+#pragma unroll
+    for (int i = 0; i < 2; ++i) own[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < a.C; ++c) {
+      const float dv = a.dy[rowc * a.C + c];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 wv = *reinterpret_cast<const float4*>(a.wout + c * D + 16 * (2 * w + i) + 4 * lg);
+        own[i][0] = fmaf(dv, wv.x, own[i][0]);
+        own[i][1] = fmaf(dv, wv.y, own[i][1]);
+        own[i][2] = fmaf(dv, wv.z, own[i][2]);
+        own[i][3] = fmaf(dv, wv.w, own[i][3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 mv = *reinterpret_cast<const float4*>(a.mask_in + rowc * D + 16 * (2 * w + i) + 4 * lg);
+      own[i][0] = mv.x > 0.f ? own[i][0] : 0.f;
+      own[i][1] = mv.y > 0.f ? own[i][1] : 0.f;
+      own[i][2] = mv.z > 0.f ? own[i][2] : 0.f;
+      own[i][3] = mv.w > 0.f ? own[i][3] : 0.f;
+    }
+  } else {  // G_ROWS_LN: LayerNorm backward (no affine): dz = rstd * (dy - mean(dy) - y * mean(dy * y)) on the FULL row
+    f32x4 gf[NB], yf[NB];
+    load_rows<NB>(gf, a.dy + rowc * D, lg);
+    load_rows<NB>(yf, a.yln + rowc * D, lg);
+    const float rs = a.rstd[rowc];
+    const float m1 = row_sum<NB>(gf) * (1.f / D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s2 = fmaf(gf[t][r], yf[t][r], s2);
+    s2 = group_sum(s2);
+    const float m2 = s2 * (1.f / D);
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gf[t][r] = rs * (gf[t][r] - m1 - yf[t][r] * m2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // own feature blocks 2w, 2w+1 (w is wave-uniform: a select over the register tile)
+      own[i] = gf[i];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (w == q) own[i] = gf[2 * q + i];
+    }
+  }
+  auto store_own = [&](float* base, const f32x4 (&v)[2]) {   // a layer gradient: rows [R, D] fp32, own quarter
+    if (!base || !live) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4*>(base + row * D + 16 * (2 * w + i) + 4 * lg));
+  };
+  FsPieces x;
+  RowScale rs{};
+  auto enter = [&](int k) {   // the gradient entering pack k: store, bound, row scale, pieces
+    store_own(a.gstore[k], own);
+    if (k > 0) lds_barrier();   // the pieces of the previous gradient have been read by everybody
+    const float m = fs_row_max(L, fs_amax2(own), w, lane);
+    fs_note(a.gmax[k], m, w, lane);
+    rs = scale_of(m);
+    fs_publish(L, x, own, rs.s, w, lane);
+  };
+  auto stage = [&](FsPack& cur, FsPack& nxt, int q, int k) {   // dgrad through layer k, masked by the ReLU sign bits of its input activation
+    if (q + 1 < a.nseq) fs_request(nxt, a.wseq[q + 1], w, lane);
+    unsigned mb = 0xffu;
+    if (a.mask[k]) mb = reinterpret_cast<const unsigned char*>(a.mask[k] + pad_rows(a.R) * D)[(rowc * 4 + lg) * 4 + w];
+    fs_stage<true, 1>(acc, cur, x, rs.E, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int keep = __builtin_amdgcn_sbfe((int)mb, 4 * i + r, 1);
+        own[i][r] = __uint_as_float(__float_as_uint(acc[i][r]) & (unsigned)keep);
+      }
+  };
+  // the two pack register sets alternate with STATIC roles (a run-time choice between them would put both in scratch)
+  auto finish = [&](FsPack& cur, FsPack& nxt, int q) {
+    if (FIRST == F_NONE) {
+      if (a.gmax[a.nstage]) {   // uniform
+        lds_barrier();
+        fs_note(a.gmax[a.nstage], fs_row_max(L, fs_amax2(own), w, lane), w, lane);
+      }
+      store_own(a.gstore[a.nstage], own);
+      return;
+    }
+    enter(a.nstage);
+    if (q + 1 < a.nseq) fs_request(nxt, a.wseq[q + 1], w, lane);
+    fs_stage<true, 1>(acc, cur, x, rs.E, lane);
+    if (a.dres && live) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] += *reinterpret_cast<const f32x4*>(a.dres + row * D + 16 * (2 * w + i) + 4 * lg);
+    }
+    if (live)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(a.dx + row * D + 16 * (2 * w + i) + 4 * lg) = acc[i];
+    if (FIRST == F_HEADS2) {
+      fs_stage<true, 1>(acc, nxt, x, rs.E, lane);
+      if (live)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(a.dx2 + row * D + 16 * (2 * w + i) + 4 * lg) = acc[i];
+    }
+  };
+  for (int k = 0;;) {
+    if (k == a.nstage) { finish(pa, pb, k); break; }
+    enter(k);
+    stage(pa, pb, k, k);
+    ++k;
+    if (k == a.nstage) { finish(pb, pa, k); break; }
+    enter(k);
+    stage(pb, pa, k, k);
+    ++k;
+  }
+}
+
 // store_pair_stream for the pipelined edge kernels: the tensor is non-null and padded (no tests), and the per-lane
 // part of both addresses is a 32-bit byte offset WITHIN THE TILE, computed once per kernel (the tile's base is uniform
 // 64-bit scalar arithmetic), so a pair costs its DPP exchange and two stores with SGPR base + VGPR offset + immediate.
@@ -2134,6 +2264,14 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
+  if constexpr (NB == 8 && (GIN == G_ROWS_LN || GIN == G_SMALL)) {   // small launches: the feature-split kernel (see launch_fwd_t)
+    static const int fs_rows = knob("BSMS_FS_ROWS", kFsMaxRows);
+    if (!a.bf16 && a.R <= fs_rows && a.nseq >= 1) {
+      hipLaunchKernelGGL((k_fs_bwd<GIN, FIRST>), dim3((unsigned)ceil_div(a.R, 16)), dim3(256), 0, s, a);
+      BSMS_LAUNCH_CHECK();
+      return BSMS_OK;
+    }
+  }
   const int cw = (GIN == G_EDGE_LN) ? knob("BSMS_BFEDGE_CW", kComputeWaves) : chain_compute_waves<NB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
   if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);

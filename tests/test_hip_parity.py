@@ -469,6 +469,15 @@ def test_feature_split_kernels_equal_the_ring_kernels(eng):
         xb = x.clone().requires_grad_(in_dim == D)
         ys, yb = mlp(xs), mlp(xb)
         assert torch.equal(ys.detach(), y_small) and torch.equal(yb.detach()[:small], y_small)     # training forward == inference forward
+        r = torch.randn(big, out_dim, device="cuda")
+        (ys * r[:small]).sum().backward()
+        gs = {k: q.grad.clone() for k, q in mlp.named_parameters()}
+        mlp.zero_grad(set_to_none=True)
+        (yb * torch.cat([r[:small], torch.zeros(big - small, out_dim, device="cuda")])).sum().backward()   # only the shared rows carry gradient
+        if in_dim == D:
+            assert torch.equal(xs.grad, xb.grad[:small]), (in_dim, out_dim)       # k_fs_bwd == k_chain_bwd bit for bit
+        for k, q in mlp.named_parameters():
+            assert rel_err(q.grad, gs[k]) < 2e-6, (in_dim, out_dim, k)            # weight gradients: other split-K slabs, round-off only
     # a GMP block: node-level chains of B = 1 (5000 rows) are feature-split, of B = 6 (30000 rows) ring kernels
     n, e = 5000, 30000
     g = random_graph(n, e, 5)
