@@ -983,7 +983,10 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
 // accumulator in the same order, same row scale, LayerNorm on the full row gathered through LDS): BIT-IDENTICAL results
 // (tests/test_hip_parity.py::test_feature_split_kernels_equal_the_ring_kernels).  Weight traffic per row is 4-14x that
 // of the persistent ring kernels, so the launcher takes this path only below kFsMaxRows rows.
-constexpr int kFsMaxRows = 12288;   // 768 tiles of 16 rows: three per CU
+// Same-box sweeps of the threshold (profiles/r04 fs_rows): airfoil B = 8 step 187.1 (never) / 188.0 (5000) / 187.3 (12288) /
+// 185.2 (24000) steps/s; B = 1 rollout 1613 (never) / 1750 (3000) / 1783 (12288): the level-0 launches of a batch-1 step
+// (5233 rows) gain, the 10 104 rows of level 2 at batch 8 do not.
+constexpr int kFsMaxRows = 6144;    // 384 tiles of 16 rows: one and a half per CU
 
 struct FsPack {           // one weight pack of the chain as wave `w` sees it
   float4 f[16];           // [chunk c][block i = 0, 1][plane h, l]  -> f[c * 4 + i * 2 + plane]
@@ -1008,14 +1011,32 @@ __device__ __forceinline__ void fs_request(FsPack& p, const float4* wp, int w, i
 // the four K blocks of the activation entering a Linear, as B operands
 struct FsPieces { u32x4 h[4], l[4]; };
 
-// One Linear on the own feature blocks.  ZERO / FIN as in mfma_stage.
+// One Linear on the own feature blocks.  ZERO / FIN as in mfma_stage.  `next` / `wnext` (nullable, uniform): the NEXT pack of
+// the chain is requested chunk by chunk between this pack's MFMAs -- a lone wave issues a 1 KB global load per ~75 cycles
+// (profiles/fs_timeline.py: 1.4k cycles for the 19 loads of a pack, against 430 for its 24 MFMAs), so the matrix
+// instructions execute under the load issue instead of after it.
 template <bool ZERO, int FIN>
-__device__ __forceinline__ void fs_stage(f32x4 (&acc)[2], const FsPack& p, const FsPieces& x, int E, int lane) {
+__device__ __forceinline__ void fs_stage(f32x4 (&acc)[2], const FsPack& p, const FsPieces& x, int E, int lane,
+                                         FsPack* next = nullptr, const float4* wnext = nullptr, int w = 0) {
+  using R = Ring<8>;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const float4* nbody = wnext ? wnext + kChunkHdrFloats / 4 + lane : nullptr;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i] = mma(p.f[c * 4 + i * 2], x.l[c], (ZERO && c == 0) ? zero : acc[i]);
+    if (wnext) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) next->f[c * 4 + i * 2 + pl] = nbody[size_t(c) * R::CH4 + ((2 * w + i) * 2 + pl) * 64];
+      if (c == 3) {
+        const float* hdr_last = reinterpret_cast<const float*>(wnext + size_t(R::NCH - 1) * R::CH4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) next->bias[i] = *reinterpret_cast<const float4*>(hdr_last + 16 * (2 * w + i) + 4 * (lane >> 4));
+        next->scale = reinterpret_cast<const float*>(wnext)[kScaleSlot];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i] = mma(p.f[c * 4 + i * 2], x.h[c], acc[i]);
 #pragma unroll
@@ -1117,6 +1138,13 @@ __global__ __launch_bounds__(256) void k_fs_fwd(ChainFwdArgs a) {
   const int64_t row = int64_t(blockIdx.x) * 16 + (lane & 15);
   const bool live = row < a.R;
   const int64_t rowc = live ? row : 0;   // what a lane past the end reads (its results are never stored)
+#ifdef BSMS_EXPERIMENTS
+  int stamp_i = 0;
+  auto stamp = [&]() { if (a.timing && tid == 0 && stamp_i < 16) a.timing[int64_t(blockIdx.x) * 16 + stamp_i++] = __builtin_amdgcn_s_memtime(); };
+#else
+  auto stamp = [] {};
+#endif
+  stamp();
   FsPack pa, pb;                         // packs alternate between the two register sets, one Linear ahead
   fs_request(pa, a.wseq[0], w, lane);
   f32x4 own[2], acc[2];
@@ -1154,16 +1182,19 @@ __global__ __launch_bounds__(256) void k_fs_fwd(ChainFwdArgs a) {
   }
   float mloc = fs_amax2(own);
   if (IN == IN_ROWS2) mloc = fmaxf(mloc, fs_amax2(own2));
+  stamp();   // loads issued
   m = fs_row_max(L, mloc, w, lane);
+  stamp();   // input rows arrived, row maximum exchanged
   fs_note(a.amax[0], m, w, lane);
   RowScale rs = scale_of(m);
   fs_publish(L, x, own, rs.s, w, lane);
+  stamp();   // pieces exchanged
 
   // ---- Linears.  `q` walks the pack sequence (a.wseq: IN_ROWS2 has two packs for its first Linear, OUT_PLAIN2 one per head)
   auto run = [&](FsPack& cur, FsPack& nxt, int q, int l) -> bool {   // returns false when the chain is finished
-    if (q + 1 < a.nseq) fs_request(nxt, a.wseq[q + 1], w, lane);
+    const float4* wn = q + 1 < a.nseq ? a.wseq[q + 1] : nullptr;     // the next pack is requested between this pack's MFMAs
     if (OUT == OUT_PLAIN2) {   // two Linears of the SAME rows: stage q -> y (q = 0) / y2 (q = 1)
-      fs_stage<true, 2>(acc, cur, x, rs.E, lane);
+      fs_stage<true, 2>(acc, cur, x, rs.E, lane, &nxt, wn, w);
       float* y = q == 0 ? a.y : a.y2;
       if (live)
 #pragma unroll
@@ -1171,13 +1202,16 @@ __global__ __launch_bounds__(256) void k_fs_fwd(ChainFwdArgs a) {
       return q + 1 < a.nseq;
     }
     if (IN == IN_ROWS2 && q == 0) {   // first half of the Linear over [x, x2]: raw sums, continued by the second pack
-      fs_stage<true, 0>(acc, cur, x, rs.E, lane);
+      fs_stage<true, 0>(acc, cur, x, rs.E, lane, &nxt, wn, w);
+      stamp();
       lds_barrier();                  // everybody has read the pieces of x
       fs_publish(L, x, own2, rs.s, w, lane);
+      stamp();
       return true;
     }
-    if (IN == IN_ROWS2 && q == 1) fs_stage<false, 2>(acc, cur, x, rs.E, lane);
-    else fs_stage<true, 2>(acc, cur, x, rs.E, lane);
+    if (IN == IN_ROWS2 && q == 1) fs_stage<false, 2>(acc, cur, x, rs.E, lane, &nxt, wn, w);
+    else fs_stage<true, 2>(acc, cur, x, rs.E, lane, &nxt, wn, w);
+    stamp();   // MFMAs of the pack issued (the wave has its weights)
     const bool last = l == a.nstage - 1;
     if (!last || OUT == OUT_SMALL) {
 #pragma unroll
@@ -1192,6 +1226,7 @@ __global__ __launch_bounds__(256) void k_fs_fwd(ChainFwdArgs a) {
     fs_note(a.amax[l + 1], m, w, lane);
     rs = scale_of(m);
     fs_publish(L, x, own, rs.s, w, lane);
+    stamp();   // next activation exchanged
     return true;
   };
   {
@@ -1466,10 +1501,9 @@ __global__ __launch_bounds__(256) void k_fs_bwd(ChainBwdArgs a) {
     fs_publish(L, x, own, rs.s, w, lane);
   };
   auto stage = [&](FsPack& cur, FsPack& nxt, int q, int k) {   // dgrad through layer k, masked by the ReLU sign bits of its input activation
-    if (q + 1 < a.nseq) fs_request(nxt, a.wseq[q + 1], w, lane);
     unsigned mb = 0xffu;
     if (a.mask[k]) mb = reinterpret_cast<const unsigned char*>(a.mask[k] + pad_rows(a.R) * D)[(rowc * 4 + lg) * 4 + w];
-    fs_stage<true, 1>(acc, cur, x, rs.E, lane);
+    fs_stage<true, 1>(acc, cur, x, rs.E, lane, &nxt, q + 1 < a.nseq ? a.wseq[q + 1] : nullptr, w);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1489,8 +1523,7 @@ __global__ __launch_bounds__(256) void k_fs_bwd(ChainBwdArgs a) {
       return;
     }
     enter(a.nstage);
-    if (q + 1 < a.nseq) fs_request(nxt, a.wseq[q + 1], w, lane);
-    fs_stage<true, 1>(acc, cur, x, rs.E, lane);
+    fs_stage<true, 1>(acc, cur, x, rs.E, lane, &nxt, q + 1 < a.nseq ? a.wseq[q + 1] : nullptr, w);
     if (a.dres && live) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] += *reinterpret_cast<const f32x4*>(a.dres + row * D + 16 * (2 * w + i) + 4 * lg);
@@ -2179,7 +2212,7 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   }
   if constexpr (NB == 8 && (IN == IN_ROWS || IN == IN_ROWS2 || IN == IN_SMALL)) {   // small launches: the feature-split kernel
     static const int fs_rows = knob("BSMS_FS_ROWS", kFsMaxRows);
-    if (!a.bf16 && !a.timing && a.R <= fs_rows && a.nseq >= 1 && a.nseq <= kMaxStages + 1) {
+    if (!a.bf16 && a.R <= fs_rows && a.nseq >= 1 && a.nseq <= kMaxStages + 1) {
       hipLaunchKernelGGL((k_fs_fwd<IN, OUT>), dim3((unsigned)ceil_div(a.R, 16)), dim3(256), 0, s, a);
       BSMS_LAUNCH_CHECK();
       return BSMS_OK;
