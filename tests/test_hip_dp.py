@@ -39,6 +39,8 @@ def _worker(rank, world, port, out_path):
     data = (c(z.t("node_in")[sl]), c(z.t("tar")[sl]), c(z.t("mask")[sl]),
             [c(e.unsqueeze(0)) for e in es], [c(i.unsqueeze(0)) for i in ids])
     engine = eng.DataParallel(sim, bucket_bytes=64 << 10)
+    engine.fused.force_overlap = True                   # the per-bucket overlapped all-reduce (default on nccl only), on gloo here
+    assert len(engine.grads.buckets) > 3 and any(e is not None for e in engine.fused._bucket_schedule(3))
     loss = engine.step_loss_backward(data, True)
     flat = engine.grads.flat.clone()
     # one fused optimizer step on the reduced gradients: parameters must stay identical across ranks
@@ -202,3 +204,48 @@ def test_rollout_trajectories_shard_across_ranks(tmp_path):
         for r in (r0, r1):
             assert torch.allclose(r["summary"][name][0].cpu(), mean, rtol=1e-5, atol=1e-9), name
             assert torch.equal(r["summary"][name][0], r0["summary"][name][0]), name
+
+
+def _probe_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from conftest import Golden
+    from oracle import bsms_oracle as ro
+    import bsms_gnn_amd as eng
+    z, graphs = Golden("sim"), Golden("graphs")
+    es, ids = graphs.levels("del300")
+    sim = eng.BSMS_Simulator(ro.make_cfg(2, 32, 3, 3, 2))
+    sim.load_state_dict(z.state_dict())
+    sim = sim.cuda()
+    c = lambda t: t.cuda()
+    sl = slice(rank, rank + 1)
+    data = (c(z.t("node_in")[sl]), c(z.t("tar")[sl]), c(z.t("mask")[sl]), [c(e.unsqueeze(0)) for e in es], [c(i.unsqueeze(0)) for i in ids])
+    engine = eng.DataParallel(sim, bucket_bytes=64 << 10)
+    engine.fused.probe_any_backend = True               # the nccl-only self-check of the overlapped all-reduce, exercised on gloo
+    losses, flats = [], []
+    for _ in range(6):
+        losses.append(float(engine.step_loss_backward(data, True)))
+        flats.append(engine.grads.flat.clone().cpu())
+    st = engine.fused._ov_probe
+    torch.save({"losses": losses, "flats": flats, "use": st["use"], "n": st["n"], "ms": st.get("measured_ms")}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_overlap_self_check_decides_once_and_identically(tmp_path):
+    """step.FusedStep._overlap_now: the first four data-parallel steps measure the plain and the per-bucket overlapped
+    gradient all-reduce (two each), the ranks agree on ONE decision, and every step -- whichever form it took -- produces
+    the same reduced gradients (the model does not change between these steps)."""
+    port = 29750 + os.getpid() % 40
+    out = str(tmp_path / "probe")
+    mp.start_processes(_probe_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["n"] == 4 and r0["use"] is not None and r0["use"] == r1["use"] and r0["ms"] == r1["ms"]
+    for k in range(6):
+        assert torch.equal(r0["flats"][k], r1["flats"][k]) and r0["losses"][k] == r1["losses"][k]      # ranks agree bit for bit
+        assert torch.equal(r0["flats"][k], r0["flats"][0])                                             # plain == overlapped form
+    print(f"\nself-check on gloo: plain {r0['ms']['plain']:.2f} ms, overlapped {r0['ms']['overlapped']:.2f} ms per step -> overlap {'kept' if r0['use'] else 'dropped'}")
