@@ -8,3 +8,4 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ou
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o r -- python bench.py --roofline-only > $out/write.log 2>&1
 python profiles/pmc_traffic.py $out/fetch/r_counter_collection.csv $out/write/r_counter_collection.csv $out/stats/r_kernel_stats.csv $tag | tee $out/traffic.json
 cp profiles/aggregation_traffic.json profiles/${tag}_aggregation_pmc.csv $out/
+cp $out/stats/r_kernel_stats.csv $out/${tag}_roofline_only_kernel_stats.csv

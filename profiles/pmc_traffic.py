@@ -18,6 +18,15 @@ avg_us = None
 for r in csv.DictReader(open(sys.argv[3])):
     if KERNEL in r["Name"]:
         avg_us = float(r["AverageNs"]) / 1e3
+# the cold launches of the same command from the kernel trace next to the stats file (bench.py --roofline-only: 65 + 65 cold
+# launches first, then the warm ones): what bench.py's `roofline.avg_us` has to agree with
+cold_us = None
+trace = sys.argv[3].replace("_kernel_stats.csv", "_kernel_trace.csv")
+if os.path.exists(trace):
+    rows = sorted((r for r in csv.DictReader(open(trace)) if KERNEL in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    if len(d) >= 130:
+        cold_us = sum(d[5:65] + d[70:130]) / 120
 f, w = sum(fetch) / len(fetch), sum(write) / len(write)
 rd, wr = 2 * f * 1024, w * 1024
 out = {"kernel": KERNEL.replace(", ", ",") + " at airfoil L0 (B=8, E=31354, N=5233, D=128), bsms_segment_sum_fwd plan order",
@@ -25,7 +34,7 @@ out = {"kernel": KERNEL.replace(", ", ",") + " at airfoil L0 (B=8, E=31354, N=52
        "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w,
        "correction": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced 16 B/lane read -> doubled; unit KiB",
        "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes": 150006704,
-       "rocprof_avg_duration_us": avg_us, "launches": len(fetch)}
+       "rocprof_avg_duration_us": avg_us, "rocprof_cold_avg_duration_us": cold_us, "launches": len(fetch)}
 here = os.path.dirname(os.path.abspath(__file__))
 json.dump(out, open(os.path.join(here, "aggregation_traffic.json"), "w"), indent=1)
 tag = sys.argv[4] if len(sys.argv) > 4 else "r01"
