@@ -987,6 +987,10 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
 // 185.2 (24000) steps/s; B = 1 rollout 1613 (never) / 1750 (3000) / 1783 (12288): the level-0 launches of a batch-1 step
 // (5233 rows) gain, the 10 104 rows of level 2 at batch 8 do not.
 constexpr int kFsMaxRows = 6144;    // 384 tiles of 16 rows: one and a half per CU
+// The backward form re-reads the full dy / y rows in every wave and runs at 256 VGPRs: per level of the batch-1 / batch-8
+// traces it wins up to ~2600 rows (14.3-16.6 us against ~19.6 for the single-round ring kernel) and loses at 4728-5233 rows
+// (24.7-29.4 against 20-23 us).
+constexpr int kFsMaxRowsBwd = 3072;
 
 struct FsPack {           // one weight pack of the chain as wave `w` sees it
   float4 f[16];           // [chunk c][block i = 0, 1][plane h, l]  -> f[c * 4 + i * 2 + plane]
@@ -2298,7 +2302,7 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   if constexpr (NB == 8 && (GIN == G_ROWS_LN || GIN == G_SMALL)) {   // small launches: the feature-split kernel (see launch_fwd_t)
-    static const int fs_rows = knob("BSMS_FS_ROWS", kFsMaxRows);
+    static const int fs_rows = knob("BSMS_FS_ROWS_BWD", kFsMaxRowsBwd);
     if (!a.bf16 && a.R <= fs_rows && a.nseq >= 1) {
       hipLaunchKernelGGL((k_fs_bwd<GIN, FIRST>), dim3((unsigned)ceil_div(a.R, 16)), dim3(256), 0, s, a);
       BSMS_LAUNCH_CHECK();

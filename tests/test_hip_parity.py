@@ -458,7 +458,7 @@ def test_feature_split_kernels_equal_the_ring_kernels(eng):
     weight gradients of the two paths agree to round-off.  MLP shapes of the path (encoder, decoder, D -> D with
     LayerNorm) and a whole GMP block at batch 1 against the same sample inside a batch of 6."""
     torch.manual_seed(21)
-    D, small, big = 128, 5000, 30000
+    D, small, big = 128, 3000, 30000      # 3000 rows: feature-split forward (<= 6144) AND backward (<= 3072)
     for in_dim, out_dim, ln in ((3, D, True), (D, D, True), (D, 3, False)):
         mlp = eng.MLP(in_dim, D, out_dim, 3, ln).cuda()
         x = torch.randn(big, in_dim, device="cuda")
@@ -478,8 +478,8 @@ def test_feature_split_kernels_equal_the_ring_kernels(eng):
             assert torch.equal(xs.grad, xb.grad[:small]), (in_dim, out_dim)       # k_fs_bwd == k_chain_bwd bit for bit
         for k, q in mlp.named_parameters():
             assert rel_err(q.grad, gs[k]) < 2e-6, (in_dim, out_dim, k)            # weight gradients: other split-K slabs, round-off only
-    # a GMP block: node-level chains of B = 1 (5000 rows) are feature-split, of B = 6 (30000 rows) ring kernels
-    n, e = 5000, 30000
+    # a GMP block: node-level chains of B = 1 (3000 rows) are feature-split, of B = 6 (18000 rows) ring kernels
+    n, e = 3000, 18000
     g = random_graph(n, e, 5)
     gmp = eng.GMP(D, 3, 2).cuda()
     x6, pos6 = torch.randn(6, n, D, device="cuda"), torch.rand(6, n, 2, device="cuda")
