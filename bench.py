@@ -474,6 +474,9 @@ def main():
     def step():
         return dp.step_loss_backward(data, consistent)
 
+    if world > 1:          # FusedStep measures its two all-reduce forms during its first four data-parallel steps (synchronised): before the warm-up
+        for _ in range(4):
+            step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -530,7 +533,10 @@ def main():
             "host_enqueue_ms_per_step": host_ms,
         }
         if world > 1:
+            probe = getattr(dp.fused, "_ov_probe", None) if dp.fused is not None else None
             line["distributed"] = {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+                                   "gradient_allreduce": ("per bucket under the backward" if probe and probe.get("use") else "one message after the backward"),
+                                   "allreduce_self_check_ms": None if not probe else probe.get("measured_ms"),
                                    "launcher": os.environ.get("BSMS_BENCH_LAUNCHER", "torch.distributed.run"),
                                    "devices": torch.cuda.device_count(),
                                    "note": None if backend == "nccl" else
