@@ -28,8 +28,5 @@ for _ in range(3):
     loss = dp.step_loss_backward(data, True)
 torch.cuda.synchronize()
 out = {"loss": torch.as_tensor(loss).detach().cpu().reshape(-1), "flat": dp.grads.flat.detach().cpu().clone()}
-with torch.inference_mode():
-    pred = sim(data, False, False)
-out["pred"] = (pred[0] if isinstance(pred, (tuple, list)) else pred).detach().cpu()
 torch.save(out, sys.argv[2])
 print("saved", sys.argv[2], float(out["loss"][0]), float(out["flat"].norm()))
