@@ -257,7 +257,7 @@ def roofline_objects(wl, batch, dtype="f32"):
     g0 = wl["m_gs"][0][0]
     plan = eng.plan_for(g0, n0)
     L = _abi.lib()
-    bf = dtype == "bf16"
+    bf = dtype != "f32"
     s = 2 if bf else 4
     algo = batch * e0 * D * s + batch * n0 * D * 4 + 4 * (n0 + 1) + 4 * e0   # SURVEY.md section 8(d); the sums stay fp32
     # COLD: rotate over enough message buffers that a launch never finds its input in the 256 MiB memory-side cache
@@ -419,7 +419,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="batch per GPU")
     ap.add_argument("--layout", default="dense", choices=["dense", "blockdiag"],
                     help="dense: consistent mesh [B,N,.]; blockdiag: B different meshes as one block-diagonal graph")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16_nodes"],
                     help="f32: the reference's arithmetic (the headline line).  bf16: BSMS_BF16 precision of the U-Net "
                          "(BASELINE configs[2]/[4]; a SEPARATE line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -521,6 +521,10 @@ def main():
                                  "what": "every timed step bracketed by HIP events on the launching stream (rank 0 min / p90; median = max over ranks)"},
             "arithmetic": ("fp32 in/out/accumulate; matrix products as three partial products of two-way fp16 splits of power-of-two-scaled fp32 operands on v_mfma_f32_16x16x32_f16 (error <= f32 MFMA and <= fp32 FMA chain, profiles/census/f16split.hip)"
                            if args.dtype == "f32" else
+                           "BSMS_BF16_NODES: BSMS_BF16 plus the node MLP -- its Linears multiply bf16 operands ([x, aggr] and hidden activations "
+                           "rounded as they enter, fp32 accumulation), hidden activations and layer gradients gN[1..H] stored as bf16; block "
+                           "input / output rows, residuals, projections, LayerNorm, aggregation sums, encoder / decoder, loss fp32"
+                           if args.dtype == "bf16_nodes" else
                            "BSMS_BF16: edge activations / messages / edge layer gradients stored as bf16, edge-MLP products bf16 x bf16 "
                            "with fp32 accumulation; node level, LayerNorm, aggregation sums, encoder / decoder, loss, weight-gradient "
                            "accumulators fp32 (no reference parity target: the reference is fp32 only)"),

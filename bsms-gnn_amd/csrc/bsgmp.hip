@@ -145,7 +145,7 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
   Shape s;
   int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_fwd");
   if (rc) return rc;
-  BSMS_REQUIRE(precision == BSMS_F32 || precision == BSMS_BF16, BSMS_E_UNSUPPORTED, "bsgmp_fwd: precision %d", precision);
+  BSMS_REQUIRE(precision == BSMS_F32 || precision == BSMS_BF16 || precision == BSMS_BF16_NODES, BSMS_E_UNSUPPORTED, "bsgmp_fwd: precision %d", precision);
   s.prec = precision;
   BSMS_REQUIRE(h && pos && params && out && work && (ew || L == 0), BSMS_E_INVALID_ARG, "bsgmp_fwd: null argument");
   hipStream_t st = as_stream(stream);
@@ -249,7 +249,7 @@ extern "C" int bsms_bsgmp_bwd_ev(const bsms_plan_t* const* plans, const float* c
   Shape s;
   int rc = make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_bwd");
   if (rc) return rc;
-  BSMS_REQUIRE(precision == BSMS_F32 || precision == BSMS_BF16, BSMS_E_UNSUPPORTED, "bsgmp_bwd: precision %d", precision);
+  BSMS_REQUIRE(precision == BSMS_F32 || precision == BSMS_BF16 || precision == BSMS_BF16_NODES, BSMS_E_UNSUPPORTED, "bsgmp_bwd: precision %d", precision);
   s.prec = precision;
   BSMS_REQUIRE(h && pos && grad_out && params && saved && work && grad_h && grads && (ew || L == 0), BSMS_E_INVALID_ARG,
                "bsgmp_bwd: null argument");

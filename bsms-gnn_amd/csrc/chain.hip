@@ -857,7 +857,17 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
   }
   for (int l = 0; l < a.nstage; ++l) {
     if constexpr (BF) {
-      mfma_stage_bf<NB>(acc, act, ring, slot, lane, true, pending, roff, (a.store_mode & 4) ? 0 : a.R);   // acc = bias + W act
+      if (IN == IN_ROWS2 && l == 0) {   // BSMS_BF16_NODES: Linear over [x, x2], both rounded to bf16 as they enter; the bias rides in the FIRST pack
+        float m = row_amax<NB>(act);
+        load_rows<NB>(acc, a.x2 + rowc * D, lg);
+        m = fmaxf(m, row_amax<NB>(acc));
+        note_amax(brow, 0, m, lane);      // bound of the fp32 rows [x, x2]: operands of the first Linear's fp32 weight-gradient job
+        mfma_stage_bf<NB>(acc, act, ring, slot, lane, true, nullptr, roff, 0);
+        load_rows<NB>(act, a.x2 + rowc * D, lg);
+        mfma_stage_bf<NB>(acc, act, ring, slot, lane, false, nullptr, roff, 0);
+      } else {
+        mfma_stage_bf<NB>(acc, act, ring, slot, lane, true, pending, roff, (a.store_mode & 4) ? 0 : a.R);   // acc = bias + W act
+      }
     } else if (IN == IN_ROWS2 && l == 0) {
       // Linear over the concatenation [x, x2]: ONE row scale (the larger of the two rows' maxima; the second source is
       // read once more for it -- node-level rows, L2-resident) and one weight scale (PackDesc::mate), so the second half
@@ -927,7 +937,7 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     for (int t = 0; t < NB; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] *= rstd;
-    if constexpr (BF) {   // edge messages of the bf16 precision: stored (and consumed by the aggregation) as bf16
+    if constexpr (BF && IN == IN_EDGE) {   // edge messages of the bf16 precision: stored (and consumed by the aggregation) as bf16
       store_rows_bf16<NB>(acc, a.y, roff, lg);
       if (a.rstd && lg == 0) a.rstd[row] = rstd;
       continue;
@@ -1350,7 +1360,7 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
       dyrow = a.dy + rowc * D;
     }
     load_rows<NB>(g, dyrow, lg);
-    if constexpr (BF) load_rows_bf16<NB>(acc, a.yln, rowc, lg);   // the bf16 messages the forward handed to the aggregation
+    if constexpr (BF && GIN == G_EDGE_LN) load_rows_bf16<NB>(acc, a.yln, rowc, lg);   // the bf16 messages the forward handed to the aggregation
     else load_rows<NB>(acc, a.yln + rowc * D, lg);  // acc = normalised output y
     const float rs = a.rstd[rowc];
     __builtin_amdgcn_sched_barrier(0);         // all 17 loads in flight before the first use (see k_chain_fwd)
@@ -1398,7 +1408,25 @@ __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_e
     pending = a.gstore[k + 1];
   }
 
-  if (FIRST != F_NONE) {
+  if constexpr (FIRST != F_NONE && BF) {   // BSMS_BF16_NODES: gN[0] stays fp32 (its weight-gradient job multiplies the fp32 rows x / aggr)
+    note_amax(brow, a.nstage, row_amax<NB>(g), lane);
+    store_rows<NB, false>(g, pending, roff, lg);
+    pending = nullptr;
+    zero_tile<NB>(acc);
+    mfma_stage_bf<NB>(acc, g, ring, slot, lane, false, nullptr, roff, 0);
+    if (a.dres) {
+      f32x4 r[NB];
+      load_rows<NB>(r, a.dres + rowc * D, lg);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) acc[t] += r[t];
+    }
+    store_rows<NB, false>(acc, a.dx, roff, lg);
+    if (FIRST == F_HEADS2) {
+      zero_tile<NB>(acc);
+      mfma_stage_bf<NB>(acc, g, ring, slot, lane, false, nullptr, roff, 0);
+      store_rows<NB, false>(acc, a.dx2, roff, lg);
+    }
+  } else if (FIRST != F_NONE) {
     const float mh = row_amax<NB>(g);
     note_amax(brow, a.nstage, mh, lane);
     const RowScale rs = scale_of(mh);
@@ -2250,7 +2278,7 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
     }
   }
 #endif
-  if constexpr ((NB == 8 || NB == 16) && IN == IN_EDGE && OUT == OUT_LN) {   // the bf16 precision exists for the edge MLP only
+  if constexpr ((NB == 8 || NB == 16) && (IN == IN_EDGE || IN == IN_ROWS2) && OUT == OUT_LN) {   // the bf16 arithmetic: edge MLP (BSMS_BF16), node MLP (BSMS_BF16_NODES)
     if (a.bf16 && !launched) {
       static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, true>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
@@ -2259,7 +2287,7 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
       launched = true;
     }
   }
-  BSMS_REQUIRE(launched || !a.bf16, BSMS_E_UNSUPPORTED, "chain_fwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
+  BSMS_REQUIRE(launched || !a.bf16, BSMS_E_UNSUPPORTED, "chain_fwd: bf16 precision is built for the edge and node MLPs at D = 128 / 256 only");
   if constexpr (NB >= 8) {   // one round of workgroups = a single wave per SIMD: the variant that prefetches its fragments (mfma_stage)
     if (!launched && a.ntiles <= device_cus()) {
       static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, false, true>),
@@ -2328,7 +2356,17 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
       return BSMS_OK;
     }
   }
-  BSMS_REQUIRE(!a.bf16, BSMS_E_UNSUPPORTED, "chain_bwd: bf16 precision is built for the edge MLP at D = 128 / 256 only");
+  if constexpr ((NB == 8 || NB == 16) && GIN == G_ROWS_LN && FIRST == F_HEADS2) {   // node MLP of BSMS_BF16_NODES
+    if (a.bf16) {
+      static const hipError_t nattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      BSMS_REQUIRE(nattr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve LDS (bf16 node build)");
+      hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
+      BSMS_LAUNCH_CHECK();
+      return BSMS_OK;
+    }
+  }
+  BSMS_REQUIRE(!a.bf16, BSMS_E_UNSUPPORTED, "chain_bwd: bf16 precision is built for the edge and node MLPs at D = 128 / 256 only");
   if constexpr (NB >= 8) {   // see launch_fwd_t
     if (a.ntiles <= device_cus()) {
       static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, false, true>),

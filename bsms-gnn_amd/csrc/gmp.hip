@@ -73,9 +73,10 @@ struct GmpSaved {
 // only the messages, the aggregate and the forward packs, carved from the scratch buffer instead.
 // `packs_base` (inference only, nullable): carve the weight packs from there instead of behind the messages, so that
 // they can be filled ahead of the call and survive the scratch reuse of other blocks.
-// `bf`: bf16 precision -- the edge activations and the messages are bf16 (half the floats; the sign bits keep their size)
+// `bf`: bf16 precision -- the edge activations and the messages are bf16 (half the floats; the sign bits keep their size);
+// `bfn` (BSMS_BF16_NODES): the node MLP's saved activations likewise
 GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H, bool training = true,
-                         void* packs_base = nullptr, bool bf = false) {
+                         void* packs_base = nullptr, bool bf = false, bool bfn = false) {
   Carver c(base);
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
@@ -87,7 +88,7 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
   if (training) s.e_fiber = c.take(re * 8);   // [B*E, fiber_ld(p)]: sized for the widest pitch (p is not part of the size query)
   s.aggr = c.take(rn * D);
   if (training) {
-    for (int l = 0; l < H; ++l) s.n_act[l] = c.take(act_floats(rn, D));
+    for (int l = 0; l < H; ++l) s.n_act[l] = c.take(bfn ? pad_rows(rn) * (size_t(D) / 2 + mask_words_per_row(D)) : act_floats(rn, D));
     s.n_yln = c.take(rn * D);
     s.n_rstd = c.take(rn);
     s.bound = c.take(size_t(kBoundSlots) * kBoundWidth);
@@ -159,13 +160,13 @@ extern "C" size_t bsms_gmp_work_bytes(int64_t B, int64_t N, int64_t E, int64_t D
 namespace {
 // where the saved tensors / packs of a forward call live (see carve_gmp_saved)
 GmpSaved locate_saved(void* saved, const GmpWork& wk, int64_t B, int64_t N, int64_t E, int64_t D, int H, void* packs_base,
-                      bool bf = false) {
-  return saved ? carve_gmp_saved(saved, B, N, E, D, H, true, nullptr, bf)
-               : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false, packs_base, bf);  // inference: lives in the gradient scratch
+                      bool bf = false, bool bfn = false) {
+  return saved ? carve_gmp_saved(saved, B, N, E, D, H, true, nullptr, bf, bfn)
+               : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false, packs_base, bf, bfn);  // inference: lives in the gradient scratch
 }
 
 int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training, const float* const* params, hipStream_t s,
-                  bool bf = false) {
+                  bool bf = false, bool bfn = false) {
   const int nl = H + 1;
   const float* const* pn = params;            // mlp_node: W_l = pn[2l], b_l = pn[2l+1]
   const float* const* pe = params + 2 * nl;   // mlp_edge
@@ -185,18 +186,23 @@ int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training
     t.d[t.n - 1].bf16 = bf;
     if (training) { add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]); t.d[t.n - 1].bf16 = bf; }
   }
-  // first node Linear over [x, aggr]: two packs, one scale; the bias rides in the second one (where the stage finishes)
-  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x);
-  add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG, sv.n_w0a, pn[1]);
+  // first node Linear over [x, aggr]: two packs, one scale; the bias rides in the second one (where the stage finishes).
+  // BSMS_BF16_NODES: one-plane packs of the rounded weights; a bf16 stage STARTS from its pack's bias (chunk 0 header), so
+  // the bias rides in the first pack there
+  add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w0x, bfn ? pn[1] : nullptr);
+  add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG, sv.n_w0a, bfn ? nullptr : pn[1]);
   t.d[t.n - 2].mate = t.n;
   t.d[t.n - 1].mate = t.n - 1;
+  t.d[t.n - 2].bf16 = t.d[t.n - 1].bf16 = bfn;
   if (training) {
     add_pack(t, pn[0], int(2 * D), 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_w0xt);
     add_pack(t, pn[0], int(2 * D), 0, (int)D, (int)D, (int)D, PACK_FRAG_T, sv.n_w0at);
+    t.d[t.n - 2].bf16 = t.d[t.n - 1].bf16 = bfn;
   }
   for (int l = 1; l <= H; ++l) {
     add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.n_w[l], pn[2 * l + 1]);
-    if (training) add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_wt[l]);
+    t.d[t.n - 1].bf16 = bfn;
+    if (training) { add_pack(t, pn[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.n_wt[l]); t.d[t.n - 1].bf16 = bfn; }
   }
   t.zero = training ? sv.bound : nullptr;
   return launch_prepack(t, s);
@@ -210,12 +216,12 @@ size_t bsms::gmp_pack_bytes(int64_t D, int hidden) {   // inference packs of one
 int bsms::gmp_prepack(int64_t B, int64_t N, int64_t E, int64_t D, int64_t p, int H, const float* const* params, void* saved,
                       void* work, void* packs_base, hipStream_t s, int precision) {
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
-  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, precision == BSMS_BF16);
-  return prepack_block(sv, D, p, H, saved != nullptr, params, s, precision == BSMS_BF16);
+  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, precision != BSMS_F32, precision == BSMS_BF16_NODES);
+  return prepack_block(sv, D, p, H, saved != nullptr, params, s, precision != BSMS_F32, precision == BSMS_BF16_NODES);
 }
 size_t bsms::gmp_saved_bytes_p(int64_t B, int64_t N, int64_t E, int64_t D, int hidden, int precision) {
   if (hidden < 1 || hidden >= kMaxStages) return 0;
-  return carve_gmp_saved(nullptr, B, N, E, D, hidden, true, nullptr, precision == BSMS_BF16).bytes;
+  return carve_gmp_saved(nullptr, B, N, E, D, hidden, true, nullptr, precision != BSMS_F32, precision == BSMS_BF16_NODES).bytes;
 }
 
 extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
@@ -231,13 +237,13 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   int rc = check_gmp(plan, B, D, p, H, "gmp_fwd");
   if (rc) return rc;
   BSMS_REQUIRE(x && pos && params && out && work, BSMS_E_INVALID_ARG, "gmp_fwd: null argument");
-  const bool bf = precision == BSMS_BF16;
+  const bool bf = precision != BSMS_F32, bfn = precision == BSMS_BF16_NODES;
   BSMS_REQUIRE(!bf || ((D == 128 || D == 256) && p <= 3), BSMS_E_UNSUPPORTED, "gmp_fwd: bf16 precision needs D = 128 / 256 and pos_dim <= 3");
   const int64_t N = plan->N, E = plan->E;
   const bool training = saved != nullptr;     // saved == NULL: inference, nothing is kept for a backward
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
-  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, bf);
-  if (do_prepack && (rc = prepack_block(sv, D, p, H, training, params, s, bf))) return rc;
+  GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, bf, bfn);
+  if (do_prepack && (rc = prepack_block(sv, D, p, H, training, params, s, bf, bfn))) return rc;
 
   // node pre-projections
   {
@@ -285,7 +291,9 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       a.store[st] = (training && st < H) ? sv.n_act[st] : nullptr;
     }
     a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x; a.resid2 = resid2;
-    if (training) for (int st = 0; st <= H; ++st) a.amax[st] = sv.bound + size_t(8 + st) * kBoundWidth;
+    a.bf16 = bfn;
+    if (training && !bfn) for (int st = 0; st <= H; ++st) a.amax[st] = sv.bound + size_t(8 + st) * kBoundWidth;
+    else if (training) a.amax[0] = sv.bound + size_t(8) * kBoundWidth;   // BSMS_BF16_NODES: only [x, aggr] feed an fp32 weight-gradient job
     a.store_mode = 1;
     a.timing = (g_debug_flags & 512) ? g_timing : nullptr;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_LN, a, s))) return rc;
@@ -326,7 +334,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
                        float* grad_x, float* const* grads, int defer_slot, hipStream_t s, int precision) {
   int rc = check_gmp(plan, B, D, p, H, "gmp_bwd");
   if (rc) return rc;
-  const bool bf = precision == BSMS_BF16;
+  const bool bf = precision != BSMS_F32, bfn = precision == BSMS_BF16_NODES;
   BSMS_REQUIRE(!bf || ((D == 128 || D == 256) && p <= 3), BSMS_E_UNSUPPORTED, "gmp_bwd: bf16 precision needs D = 128 / 256 and pos_dim <= 3");
   BSMS_REQUIRE(x && pos && grad_out && params && saved && work && grad_x && grads, BSMS_E_INVALID_ARG,
                "gmp_bwd: null argument");
@@ -335,7 +343,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   float* const* gn = grads;
   float* const* ge = grads + 2 * nl;
   const int ldE0 = int(2 * D + p + 1);
-  GmpSaved sv = carve_gmp_saved(const_cast<void*>(saved), B, N, E, D, H, true, nullptr, bf);
+  GmpSaved sv = carve_gmp_saved(const_cast<void*>(saved), B, N, E, D, H, true, nullptr, bf, bfn);
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
 
   // node MLP backward: grad_x = grad_out (residual) + g0 W0x ; daggr = g0 W0a
@@ -352,7 +360,9 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.wh0 = reinterpret_cast<const float4*>(sv.n_w0xt);
     a.wh1 = reinterpret_cast<const float4*>(sv.n_w0at);
     a.dx = grad_x; a.dx2 = wk.daggr; a.dres = grad_out;
-    for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(24 + k) * kBoundWidth;
+    a.bf16 = bfn;
+    if (!bfn) for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(24 + k) * kBoundWidth;
+    else a.gmax[H] = sv.bound + size_t(24 + H) * kBoundWidth;   // BSMS_BF16_NODES: only gN[0] (fp32) feeds an fp32 weight-gradient job
     if ((rc = launch_chain_bwd((int)D, G_ROWS_LN, F_HEADS2, a, s))) return rc;
   }
   // edge MLP backward (gradient of the aggregation = gather by target)
@@ -402,7 +412,10 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0, bd(16 + (H - l)), bd(l - 1));
       jobs[nj - 1].bf16 = bf;
     }
-    for (int l = 1; l <= H; ++l) add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0, bd(24 + (H - l)), bd(8 + l));
+    for (int l = 1; l <= H; ++l) {   // node Linears 1..H: bf16 tensors in BSMS_BF16_NODES
+      add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0, bd(24 + (H - l)), bd(8 + l));
+      jobs[nj - 1].bf16 = bfn;
+    }
     add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0, bd(24 + H), bd(8));
     add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D, bd(24 + H), bd(8));
     if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, ws))) return rc;

@@ -568,7 +568,7 @@ class InferenceSession:
         return reuse
 
 
-PRECISIONS = {"f32": 0, "bf16": 1}   # include/bsms_hip.h: bsms_precision
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16_nodes": 2}   # include/bsms_hip.h: bsms_precision (bf16: edge MLP; bf16_nodes: edge + node MLP)
 
 
 def _bsgmp_infer(h, pos, plans, ews, hidden, params, session=None, prec=0):

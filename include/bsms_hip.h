@@ -56,13 +56,18 @@ typedef enum {
   BSMS_E_HIP = -4
 } bsms_status;
 
-/* Precision of the EDGE-level tensors inside a GMP block (the *_p entries of the U-Net).  BSMS_F32 is the reference's
- * arithmetic.  BSMS_BF16 is a build extension without a reference parity target (the reference has no mixed precision):
- * the saved edge activations, the messages and the edge layer gradients are stored in HBM as bf16 (round to nearest
- * even) and the D x D Linears of the edge MLP multiply bf16 operands (weights rounded once per call) with fp32
- * accumulation; bias, ReLU, LayerNorm, the aggregation sums, every node-level tensor and kernel (projections, node
- * MLP, transitions, skip connections), the encoder / decoder and all weight-gradient accumulators stay fp32. */
-typedef enum { BSMS_F32 = 0, BSMS_BF16 = 1 } bsms_precision;
+/* Precision of the tensors inside a GMP block (the *_p entries of the U-Net).  BSMS_F32 is the reference's arithmetic.
+ * The other two are build extensions without a reference parity target (the reference has no mixed precision):
+ * BSMS_BF16: the saved EDGE activations, the messages and the edge layer gradients are stored in HBM as bf16 (round to
+ *   nearest even) and the D x D Linears of the edge MLP multiply bf16 operands (weights rounded once per call) with fp32
+ *   accumulation; bias, ReLU, LayerNorm, the aggregation sums, every node-level tensor and kernel (projections, node
+ *   MLP, transitions, skip connections), the encoder / decoder and all weight-gradient accumulators stay fp32.
+ * BSMS_BF16_NODES (round 4): BSMS_BF16 plus the NODE MLP: its four Linears multiply bf16 operands (the rows [x, aggr] and
+ *   the hidden activations rounded to bf16 as they enter a Linear, weights rounded once per call; fp32 accumulation,
+ *   bias, ReLU, LayerNorm), its hidden activations are saved as bf16 and its layer gradients gN[1..H] are stored as bf16
+ *   (one-product weight-gradient jobs); the block's input / output rows [B,N,D], the residual and skip additions, the
+ *   projections, gN[0] and the weight gradient of the first node Linear (operands x, aggr in fp32) stay fp32. */
+typedef enum { BSMS_F32 = 0, BSMS_BF16 = 1, BSMS_BF16_NODES = 2 } bsms_precision;
 
 typedef struct bsms_plan bsms_plan_t; /* one mesh level: dst-sorted CSR + src-sorted transpose */
 typedef void* bsms_stream_t;          /* hipStream_t */

@@ -49,13 +49,24 @@ class EmulatedGMP(ro.GMP):
                 a = torch.relu(a)
         msg = bf16(torch.nn.functional.layer_norm(a, a.shape[-1:]))
         aggr = ro.scatter_sum(msg, recv, dim=-2, dim_size=x.shape[-2])
-        return self.mlp_node(torch.cat([x, aggr], -1)) + x
+        if not getattr(self, "node_level", False):
+            return self.mlp_node(torch.cat([x, aggr], -1)) + x
+        # BSMS_BF16_NODES: every Linear of the node MLP multiplies bf16 operands ([x, aggr] and the hidden activations rounded
+        # as they enter, weights rounded once), fp32 accumulation / bias / ReLU / LayerNorm, fp32 residual
+        nlin = [m for m in self.mlp_node.seq if isinstance(m, torch.nn.Linear)]
+        a = torch.cat([x, aggr], -1)
+        for k, m in enumerate(nlin):
+            a = torch.nn.functional.linear(bf16(a), bf16(m.weight), m.bias)
+            if k < len(nlin) - 1:
+                a = torch.relu(a)
+        return torch.nn.functional.layer_norm(a, a.shape[-1:]) + x
 
 
-def emulate(net):
+def emulate(net, node_level=False):
     for name, mod in list(net.named_modules()):
-        if type(mod) is ro.GMP:
+        if type(mod) in (ro.GMP, EmulatedGMP):
             mod.__class__ = EmulatedGMP
+            mod.node_level = node_level
     return net
 
 
@@ -75,6 +86,16 @@ def test_bf16_forward_matches_the_documented_arithmetic(eng, graphs):
             got = mine(h.cuda(), [i.cuda() for i in ids[:depth]], [e.cuda() for e in es[: depth + 1]], pos.cuda()).cpu()
         assert rel_err(got, want) < 3e-3, (depth, D)
         assert 1e-4 < rel_err(got, want32) < 3e-2, (depth, D)          # it really is a different precision, and a usable one
+        # BSMS_BF16_NODES: the node MLP in bf16 as well, against ITS documented arithmetic
+        mine.precision = "bf16_nodes"
+        with torch.no_grad():
+            want_n = emulate(ref, node_level=True)(h, ids[:depth], es[: depth + 1], pos)
+            got_n = mine(h.cuda(), [i.cuda() for i in ids[:depth]], [e.cuda() for e in es[: depth + 1]], pos.cuda()).cpu()
+        assert rel_err(got_n, want_n) < 3e-3, (depth, D, "bf16_nodes")
+        assert 1e-4 < rel_err(got_n, want32) < 4e-2, (depth, D, "bf16_nodes")
+        assert rel_err(got_n, want) > 1e-4                             # and it is not the edge-only precision
+        emulate(ref, node_level=False)
+        mine.precision = "bf16"
         # training forward (activations saved as bf16) == inference forward, bit for bit
         hh = h.cuda().requires_grad_(True)
         y = mine(hh, [i.cuda() for i in ids[:depth]], [e.cuda() for e in es[: depth + 1]], pos.cuda())
@@ -173,7 +194,7 @@ def _fused_step_both_precisions(eng, kind, batch):
     grads = eng.GradBuckets(list(sim.parameters()))
     step = eng.FusedStep(sim, grads)
     res = {}
-    for prec in ("f32", "bf16"):
+    for prec in ("f32", "bf16", "bf16_nodes"):
         sim.process.precision = prec
         grads.flat.zero_()
         loss = step(data, True)
@@ -203,3 +224,56 @@ def test_airfoil_b8_bf16_fused_step_full_size(eng):
     assert rel_err(res["bf16"][0], res["f32"][0]) < 3e-2
     assert abs(res["bf16"][1] - res["f32"][1]) < 1e-2 * abs(res["f32"][1])
     _grads_close(res["bf16"][2], res["f32"][2], "airfoil B=8 bf16 vs fp32 engine (fused step)")
+
+
+def test_bf16_nodes_training_step_small(eng, graphs):
+    """BSMS_BF16_NODES on the 300-node golden step: forward / loss within the bf16 tolerances of the fp32 oracle, every
+    gradient finite and aligned with the fp32 one, fused step == autograd step."""
+    z = load_golden("sim")
+    es, ids = graphs.levels("del300")
+    B = z.np("node_in").shape[0]
+    cfg = ro.make_cfg(2, 128, 3, 3, 2)
+    torch.manual_seed(1)
+    ref = ro.BSMS_Simulator(cfg)
+    m_gs, m_ids = [e.unsqueeze(0).repeat(B, 1, 1) for e in es], [i.unsqueeze(0).repeat(B, 1) for i in ids]
+    data = (z.t("node_in"), z.t("tar"), z.t("mask"), m_gs, m_ids)
+    ref(data, True, True)
+    pred_ref = ref(data, True, False)
+    loss_ref = ro.masked_rmse(pred_ref, data[1], data[2])
+    loss_ref.backward()
+    want = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    mine = eng.BSMS_Simulator(cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda()
+    mine.process.precision = "bf16_nodes"
+    gdata = (data[0].cuda(), data[1].cuda(), data[2].cuda(), [g.cuda() for g in m_gs], [i.cuda() for i in m_ids])
+    pred = mine(gdata, True, False)
+    loss = eng.masked_rmse(pred, gdata[1], gdata[2])
+    loss.backward()
+    assert rel_err(pred.detach().cpu(), pred_ref.detach()) < 4e-2
+    assert abs(float(loss) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
+    got = {k: p.grad.cpu() for k, p in mine.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    _grads_close(got, want, "del300 L=3 D=128 bf16_nodes", l2_tol=0.35, cos_tol=0.94)
+    auto = {k: v.clone() for k, v in got.items()}
+    mine.zero_grad(set_to_none=True)
+    grads = eng.GradBuckets(list(mine.parameters()))
+    step = eng.FusedStep(mine, grads)
+    l2 = step(gdata, True)
+    assert abs(float(l2) - float(loss)) < 1e-6 * abs(float(loss))
+    for k, p in mine.named_parameters():
+        if p.requires_grad:
+            assert rel_err(p.grad.cpu(), auto[k]) < 5e-3, k
+
+
+def test_bf16_nodes_full_size_vs_fp32_engine(eng):
+    """BSMS_BF16_NODES at the sizes of BASELINE configs[2] and [4] through the fused step, against the fp32 engine.  Twice the
+    bf16 Linears per block of the edge-only precision: the gradient tolerance is stated for THIS mode (relative L2 8e-2,
+    cosine 0.996); prediction and loss keep the tolerances of the edge-only precision."""
+    for kind, batch in (("airfoil", 8), ("surface", 2)):
+        _, res = _fused_step_both_precisions(eng, kind, batch)
+        assert torch.isfinite(res["bf16_nodes"][0]).all()
+        assert rel_err(res["bf16_nodes"][0], res["f32"][0]) < 3e-2, kind
+        assert abs(res["bf16_nodes"][1] - res["f32"][1]) < 1e-2 * abs(res["f32"][1]), kind
+        assert set(res["bf16_nodes"][2]) == set(res["f32"][2])
+        _grads_close(res["bf16_nodes"][2], res["f32"][2], f"{kind} B={batch} bf16_nodes vs fp32 engine (fused step)", l2_tol=8e-2, cos_tol=0.996)
