@@ -32,6 +32,13 @@ int side_lane(SideLane** out, int which) {
   std::lock_guard<std::mutex> lock(g_lane_mu);
   SideLane& l = g_lanes[dev][which];
   if (!l.stream) {
+#ifdef BSMS_EXPERIMENTS
+    if (const char* e = getenv("BSMS_LANE_PRIO")) {   // A/B: lanes below / above the caller's stream (hipDeviceGetStreamPriorityRange: least .. greatest)
+      int least = 0, greatest = 0;
+      BSMS_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      BSMS_HIP_CHECK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, atoi(e) < 0 ? least : greatest));
+    } else
+#endif
     BSMS_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));   // (a lower or higher stream priority for the lanes: +-0, profiles/README.md)
     // same-device stream ordering only: no timing, and no system-scope fence when an event completes (the kernels'
     // own end-of-kernel release / start-of-kernel acquire make their data visible device-wide; the extra fence is for

@@ -366,6 +366,131 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_wgrad_bf64: the bf16 jobs (WgradJob::bf16: gradient and activation tensors stored as bf16, ONE product per fragment
+// pair) with 64-row chunks.  In k_wgrad<., true> a chunk is 32 rows = 8 KB per operand and a thread moves 8 bytes of each:
+// half the bytes in flight per CU of the fp32 form at the same step overhead, and the chunk step is paced by HBM latency
+// x bytes in flight -- 2.6-2.9 TB/s on 132 workgroups.  Here a thread moves 16 bytes of each operand per
+// chunk (rows tid / 16, columns 8 (tid % 16) ..), a chunk is two K steps of the MFMA: the same 32 KB per step and 96 KB
+// in flight as the fp32 kernel.  Same products in the same order per accumulator (chunk after chunk, rows ascending).
+constexpr int RC2 = 64;
+constexpr int PLANE2 = RC2 * LROW;
+
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_bf64(WgradTable tab) {
+  extern __shared__ __attribute__((aligned(16))) short planes[];  // [2 buffers][G|A][64 rows][LROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int j = 0;
+  while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
+  const WgradJob job = tab.job[j];
+  const int local = blockIdx.x - tab.first_tile[j];
+  const int bj = local % tab.nblk, bi = (local / tab.nblk) % tab.nblk, split = local / (tab.nblk * tab.nblk);
+  const int D = tab.D;
+  const int64_t r0 = int64_t(split) * tab.rows_per_wg[j];
+  const int64_t r1 = min(job.R, r0 + tab.rows_per_wg[j]);
+  const int nchunk = int((r1 - r0 + RC2 - 1) / RC2);
+  const int n0 = bi * TB, k0 = bj * TB;
+  float* part = tab.partials + int64_t(blockIdx.x) * (TB * TB);
+  const bool want_db = job.db && bj == 0;
+  if (nchunk == 0) {   // cannot happen for a launched slab
+    for (int o = tid; o < TB * TB; o += WG_THREADS) part[o] = 0.f;
+    if (want_db && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = 0.f;
+    return;
+  }
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  const int srow = tid >> 4, scol = (tid & 15) * 8;
+  const bool vg = n0 + scol < D, va = k0 + scol < D;
+  const unsigned short* gsrc = reinterpret_cast<const unsigned short*>(job.G) + (vg ? n0 + scol : 0);
+  const unsigned short* asrc = reinterpret_cast<const unsigned short*>(job.A) + (va ? k0 + scol : 0);
+  const int64_t rlast = r1 - 1;
+  u32x4 sg[NPF], sa[NPF];
+  bool live[NPF];
+  auto fetch = [&](int chunk, int set) {   // unconditional loads: chunks past the slab re-read its last row (never staged)
+    const int64_t r = r0 + int64_t(chunk) * RC2 + srow;
+    live[set] = r < r1;
+    const int64_t rc = r < r1 ? r : rlast;
+    sg[set] = *reinterpret_cast<const u32x4*>(gsrc + rc * job.ldg);
+    sa[set] = *reinterpret_cast<const u32x4*>(asrc + rc * job.lda);
+  };
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of G over this thread's rows
+  auto stash = [&](int set, int buf) {
+    short* dst = planes + buf * (2 * PLANE2) + srow * LROW + scol;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const u32x4 gq = (live[set] && vg) ? sg[set] : zero, aq = (live[set] && va) ? sa[set] : zero;
+    *reinterpret_cast<u32x4*>(dst) = gq;
+    *reinterpret_cast<u32x4*>(dst + PLANE2) = aq;
+    if (want_db) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        csum[2 * k] += __uint_as_float(gq[k] << 16);
+        csum[2 * k + 1] += __uint_as_float(gq[k] & 0xffff0000u);
+      }
+    }
+  };
+  const int wr = wave >> 2, wc = wave & 3;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](int buf) {
+    const short* base = planes + buf * (2 * PLANE2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {   // two K steps of 32 rows
+      const short* pg = base + ks * 32 * LROW;
+      const short* pa = base + PLANE2 + ks * 32 * LROW;
+      bf16x8 g1[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) g1[a] = column_fragment(pg, 32 * wr + 16 * a, lane);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bf16x8 a1 = column_fragment(pa, 32 * wc + 16 * b, lane);
+        acc[0][b] = mma(g1[0], a1, acc[0][b]);
+        acc[1][b] = mma(g1[1], a1, acc[1][b]);
+      }
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < NPF; ++c) fetch(c, c);
+  stash(0, 0);
+  fetch(NPF, 0);
+  wg_barrier();
+  auto step = [&](int c, auto set1_tag, auto buf_tag) {
+    constexpr int SET1 = decltype(set1_tag)::value, BUF = decltype(buf_tag)::value;
+    stash(SET1, BUF ^ 1);          // chunk c + 1 -> the other buffer (zeros past the slab)
+    fetch(c + 1 + NPF, SET1);
+    multiply(BUF);
+    wg_barrier();
+  };
+  using std::integral_constant;
+  for (int c = 0; c < nchunk; c += 6) {   // the schedule of k_wgrad: register sets and buffers compile-time in every step
+    step(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    step(c + 1, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    step(c + 2, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    step(c + 3, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    step(c + 4, integral_constant<int, 2>{}, integral_constant<int, 0>{});
+    step(c + 5, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+  }
+  const int q = lane >> 4, cc = lane & 15;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(32 * wr + 16 * a + 4 * q + r) * TB + 32 * wc + 16 * b + cc] = acc[a][b][r];
+  if (want_db) {  // the 64 row-threads of each column octet in fixed order through LDS
+    float* red = reinterpret_cast<float*>(planes);   // [64 row lanes][128 columns]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[srow * TB + scol + k] = csum[k];
+    __syncthreads();
+    if (tid < TB) {
+      float v = red[tid];
+      for (int l = 1; l < 64; ++l) v += red[l * TB + tid];
+      tab.colsums[int64_t(blockIdx.x) * TB + tid] = v;
+    }
+  }
+}
+
 // dW[n][col0+k] = sum over slabs of the partial blocks; db likewise.  A block owns 64 float4 outputs; its 4
 // "slab lanes" each sum every 4th slab (independent 16-byte loads in flight), then combine in a fixed order
 // through LDS, so the result does not depend on scheduling.
@@ -608,7 +733,8 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
   constexpr int target_wgs = 128;
 #endif
   int64_t rows_per = std::max<int64_t>(128, ceil_div(total_rows * blocks, target_wgs));
-  rows_per = ceil_div(rows_per, 6 * RC) * (6 * RC);   // whole groups of six chunks (k_wgrad's step schedule)
+  const int chunk_rows = bf ? RC2 : RC;                // bf16 jobs: 64-row chunks (k_wgrad_bf64)
+  rows_per = ceil_div(rows_per, 6 * chunk_rows) * (6 * chunk_rows);   // whole groups of six chunks (the kernels' step schedule)
   for (;;) {
     int64_t tiles = 0;
     for (int j = 0; j < njobs; ++j) tiles += std::max<int64_t>(1, ceil_div(jobs[j].R, rows_per)) * blocks;
@@ -638,6 +764,12 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     BSMS_REQUIRE(attr_h == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (fp16 x 2 build)", lds);
     hipLaunchKernelGGL((k_wgrad<false, false, true>), dim3(first), dim3(WG_THREADS), lds, s, tab);
+  } else if (bf && [] { const char* e = getenv("BSMS_WGRAD_BF64"); return !e || atoi(e) != 0; }()) {
+    const size_t lds_b = size_t(2) * 2 * PLANE2 * sizeof(short);   // 72 KB: 2 x [G|A][64 rows][288 B]
+    static const hipError_t attr_b64 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf64),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    BSMS_REQUIRE(attr_b64 == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (bf16 build, 64-row chunks)", lds_b);
+    hipLaunchKernelGGL(k_wgrad_bf64, dim3(first), dim3(WG_THREADS), lds_b, s, tab);
   } else if (bf) {
     static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<false, true>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
