@@ -52,6 +52,15 @@ def test_size_queries_and_validation_without_gpu(eng):
     assert L.bsms_plan_destroy(None) == 0 and L.bsms_plan_num_nodes(None) == -1
 
 
+def test_precision_levels_match_the_header(eng):
+    """`bsms_precision` (include/bsms_hip.h) and the Python names of the drop-in modules agree."""
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "bsms_hip.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"(BSMS_F32|BSMS_BF16_NODES|BSMS_BF16) = (\d+)", hdr))
+    from bsms_gnn_amd.ops import PRECISIONS
+    assert PRECISIONS == {"f32": enum["BSMS_F32"], "bf16": enum["BSMS_BF16"], "bf16_nodes": enum["BSMS_BF16_NODES"]}
+
+
 def test_no_cpu_fallback(eng):
     """The product path must fail loudly instead of degrading to PyTorch when used without a GPU."""
     g = torch.tensor([[0, 1], [1, 0]])
