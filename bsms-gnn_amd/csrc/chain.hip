@@ -154,6 +154,77 @@ __global__ __launch_bounds__(256) void k_prepack(PackTable tab) {
   }
 }
 
+// k_pack_scale + k_prepack in ONE launch (round 4: a training step packs 13 weight sets, three of them in front of kernels on
+// the caller's stream): every workgroup of a pack repeats the scan for the matrix maximum (64-128 KB from L2) and then writes
+// its share of the pack; same scale, same pieces, same bytes as the two-pass form.
+__global__ __launch_bounds__(1024) void k_prepack_fused(PackTable tab) {
+  const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (tab.zero)   // clear the block's bound slots (chain.h: kBoundWidth), spread over the launch
+    for (int o = wg * 1024 + threadIdx.x; o < kBoundSlots * kBoundWidth / 4; o += nwg * 1024)
+      reinterpret_cast<float4*>(tab.zero)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const PackDesc d = tab.d[blockIdx.y];
+  if (d.kind == PACK_TRANSPOSE) {
+    const int total = d.N * d.K;
+    for (int o = blockIdx.x * 1024 + threadIdx.x; o < total; o += gridDim.x * 1024) {
+      const int k = o / d.N, n = o % d.N;
+      d.dst[o] = d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
+    }
+    return;
+  }
+  float sw = 1.f;
+  unsigned hdr_scale = 0;
+  if (!d.bf16) {
+    __shared__ float red[16];
+    float m = 0.f;
+    auto scan = [&](const PackDesc& e) {   // coalesced along the rows of W whatever the logical orientation
+      const int rows = (e.kind == PACK_FRAG_T) ? e.K : e.N, cols = (e.kind == PACK_FRAG_T) ? e.N : e.K;
+      const int tr = threadIdx.x / cols, tc = threadIdx.x % cols, step = 1024 / cols;   // cols divides 1024 (32 .. 256)
+      for (int r = tr; r < rows; r += step) m = fmaxf(m, fabsf(e.W[int64_t(e.row0 + r) * e.ld + e.col0 + tc]));
+    };
+    scan(d);
+    if (d.mate) scan(tab.d[d.mate - 1]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    int Ew = int(__float_as_uint(m) >> 23);
+    Ew = Ew < 13 ? 13 : (Ew > 254 ? 254 : Ew);            // 2^(139 - Ew) and its inverse are normal floats
+    hdr_scale = unsigned(Ew - 12) << 23;                   // 2^(Ew - 139) = 2^-k_w  (header float kScaleSlot of chunk 0)
+    sw = __uint_as_float(unsigned(254 - (Ew - 12)) << 23); // 2^k_w
+  }
+  const int nb = d.N >> 4, planes = d.bf16 ? 1 : kPL, chf = kChunkHdrFloats + nb * 256 * planes, nch = d.K >> 5;
+  const int total = nch * chf;
+  unsigned* dst = reinterpret_cast<unsigned*>(d.dst);
+  for (int o = blockIdx.x * 1024 + threadIdx.x; o < total; o += gridDim.x * 1024) {
+    const int c = o / chf, w = o % chf;
+    if (w < kChunkHdrFloats) {
+      float v = 0.f;
+      if (d.bf16) {
+        if (c == 0 && d.bias && w < d.N) v = d.bias[w];
+      } else {
+        if (c == nch - 1 && d.bias && w < d.N) v = d.bias[w];
+        if (c == 0 && w == kScaleSlot) { dst[o] = hdr_scale; continue; }   // (nch == 1 means N = 32: no clash with the bias)
+      }
+      d.dst[o] = v;
+      continue;
+    }
+    const int q = w - kChunkHdrFloats;
+    const int v = q & 3, lane = (q >> 2) & 63, tp = q >> 8, plane = tp % planes, t = tp / planes;
+    const int n = 16 * t + (lane & 15), k = 16 * (2 * c + ((2 * v) >> 2)) + 4 * (lane >> 4) + ((2 * v) & 3);   // slots 2v, 2v + 1
+    const float x0 = pack_elem(d, n, k), x1 = pack_elem(d, n, k + 1);
+    if (d.bf16) {
+      dst[o] = pk_bf16(x0, x1);
+    } else {
+      unsigned h, l;
+      split_h2(x0, x1, sw, h, l);
+      dst[o] = plane == 0 ? h : l;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------ register-tile helpers
 template <int NB>
 __device__ __forceinline__ void zero_tile(f32x4 (&v)[NB]) {
@@ -2413,6 +2484,12 @@ int launch_prepack(const PackTable& t, hipStream_t s) {
   if (t.n == 0) return BSMS_OK;
   int biggest = 0;
   for (int i = 0; i < t.n; ++i) biggest = biggest > t.d[i].N * t.d[i].K ? biggest : t.d[i].N * t.d[i].K;
+  static const int fused = knob("BSMS_PACK_FUSED", 1);
+  if (fused) {
+    hipLaunchKernelGGL(k_prepack_fused, dim3((unsigned)std::min<int64_t>(ceil_div(biggest, 4096), 16), t.n), dim3(1024), 0, s, t);
+    BSMS_LAUNCH_CHECK();
+    return BSMS_OK;
+  }
   const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(biggest, 256), 64);
   hipLaunchKernelGGL(k_pack_scale, dim3(t.n), dim3(1024), 0, s, t);
   BSMS_LAUNCH_CHECK();
