@@ -179,7 +179,16 @@ __global__ __launch_bounds__(1024) void k_prepack_fused(PackTable tab) {
     auto scan = [&](const PackDesc& e) {   // coalesced along the rows of W whatever the logical orientation
       const int rows = (e.kind == PACK_FRAG_T) ? e.K : e.N, cols = (e.kind == PACK_FRAG_T) ? e.N : e.K;
       const int tr = threadIdx.x / cols, tc = threadIdx.x % cols, step = 1024 / cols;   // cols divides 1024 (32 .. 256)
-      for (int r = tr; r < rows; r += step) m = fmaxf(m, fabsf(e.W[int64_t(e.row0 + r) * e.ld + e.col0 + tc]));
+      const float* base = e.W + int64_t(e.row0) * e.ld + e.col0 + tc;
+      int r = tr;
+      for (; r + 7 * step < rows; r += 8 * step) {   // eight independent loads in flight (one at a time: 16-64 dependent L2 round trips)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[int64_t(r + u * step) * e.ld];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(v[u]));
+      }
+      for (; r < rows; r += step) m = fmaxf(m, fabsf(base[int64_t(r) * e.ld]));
     };
     scan(d);
     if (d.mate) scan(tab.d[d.mate - 1]);
@@ -198,29 +207,48 @@ __global__ __launch_bounds__(1024) void k_prepack_fused(PackTable tab) {
   const int nb = d.N >> 4, planes = d.bf16 ? 1 : kPL, chf = kChunkHdrFloats + nb * 256 * planes, nch = d.K >> 5;
   const int total = nch * chf;
   unsigned* dst = reinterpret_cast<unsigned*>(d.dst);
-  for (int o = blockIdx.x * 1024 + threadIdx.x; o < total; o += gridDim.x * 1024) {
-    const int c = o / chf, w = o % chf;
-    if (w < kChunkHdrFloats) {
-      float v = 0.f;
-      if (d.bf16) {
-        if (c == 0 && d.bias && w < d.N) v = d.bias[w];
-      } else {
-        if (c == nch - 1 && d.bias && w < d.N) v = d.bias[w];
-        if (c == 0 && w == kScaleSlot) { dst[o] = hdr_scale; continue; }   // (nch == 1 means N = 32: no clash with the bias)
+  // four pack dwords per round: their eight weight loads are in flight together
+  const int stride = gridDim.x * 1024;
+  for (int o0 = blockIdx.x * 1024 + threadIdx.x; o0 < total; o0 += 4 * stride) {
+    float x0[4], x1[4];
+    bool body_[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * stride, w = o % chf;
+      body_[u] = o < total && w >= kChunkHdrFloats;
+      x0[u] = x1[u] = 0.f;
+      if (body_[u]) {
+        const int c = o / chf, q = w - kChunkHdrFloats;
+        const int v = q & 3, lane = (q >> 2) & 63, tp = q >> 8, t = tp / planes;
+        const int n = 16 * t + (lane & 15), k = 16 * (2 * c + ((2 * v) >> 2)) + 4 * (lane >> 4) + ((2 * v) & 3);   // slots 2v, 2v + 1
+        x0[u] = pack_elem(d, n, k);
+        x1[u] = pack_elem(d, n, k + 1);
       }
-      d.dst[o] = v;
-      continue;
     }
-    const int q = w - kChunkHdrFloats;
-    const int v = q & 3, lane = (q >> 2) & 63, tp = q >> 8, plane = tp % planes, t = tp / planes;
-    const int n = 16 * t + (lane & 15), k = 16 * (2 * c + ((2 * v) >> 2)) + 4 * (lane >> 4) + ((2 * v) & 3);   // slots 2v, 2v + 1
-    const float x0 = pack_elem(d, n, k), x1 = pack_elem(d, n, k + 1);
-    if (d.bf16) {
-      dst[o] = pk_bf16(x0, x1);
-    } else {
-      unsigned h, l;
-      split_h2(x0, x1, sw, h, l);
-      dst[o] = plane == 0 ? h : l;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * stride;
+      if (o >= total) break;
+      const int c = o / chf, w = o % chf;
+      if (!body_[u]) {   // chunk header
+        float v = 0.f;
+        if (d.bf16) {
+          if (c == 0 && d.bias && w < d.N) v = d.bias[w];
+        } else {
+          if (c == nch - 1 && d.bias && w < d.N) v = d.bias[w];
+          if (c == 0 && w == kScaleSlot) { dst[o] = hdr_scale; continue; }   // (nch == 1 means N = 32: no clash with the bias)
+        }
+        d.dst[o] = v;
+        continue;
+      }
+      const int plane = ((w - kChunkHdrFloats) >> 8) % planes;
+      if (d.bf16) {
+        dst[o] = pk_bf16(x0[u], x1[u]);
+      } else {
+        unsigned h, l;
+        split_h2(x0[u], x1[u], sw, h, l);
+        dst[o] = plane == 0 ? h : l;
+      }
     }
   }
 }
