@@ -515,7 +515,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradTable tab) {
       base = tab.colsums + int64_t(tab.first_tile[j] + bi * nblk) * TB + (n % TB);
       stride = int64_t(nblk) * nblk * TB;
     }
-    for (int sp = sl; sp < ns; sp += 4) {
+    int sp = sl;
+    for (; sp + 12 < ns; sp += 16) {   // four slabs per round: the loads first (one at a time this loop is 8-11 dependent round trips), the adds in slab order
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + (sp + 4 * u) * stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; sp < ns; sp += 4) {
       const float4 v = *reinterpret_cast<const float4*>(base + sp * stride);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
