@@ -421,7 +421,7 @@ def main():
                     help="dense: consistent mesh [B,N,.]; blockdiag: B different meshes as one block-diagonal graph")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16_nodes"],
                     help="f32: the reference's arithmetic (the headline line).  bf16: BSMS_BF16 precision of the U-Net "
-                         "(BASELINE configs[2]/[4]; a SEPARATE line)")
+                         "(BASELINE configs[2]/[4]; a SEPARATE line).  bf16_nodes: BSMS_BF16_NODES (node MLP in bf16 too)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the kernel micro-loops (for rocprofv3 --pmc passes)")

@@ -609,7 +609,8 @@ class BSGMP(nn.Module):
         self.latent_dim, self.pos_dim = latent_dim, pos_dim
         self.per_block = _PY_BSGMP   # True: one autograd node per block / transition (module tree) instead of one call
         # "f32": the reference's arithmetic.  "bf16" (one-call path only): edge-level tensors stored as bf16, bf16 operands
-        # in the edge MLP, fp32 accumulation and fp32 everywhere at node level (include/bsms_hip.h: bsms_precision)
+        # in the edge MLP, fp32 accumulation and fp32 everywhere at node level.  "bf16_nodes": the node MLP of every block in
+        # that arithmetic as well (include/bsms_hip.h: bsms_precision)
         self.precision = os.environ.get("BSMS_PRECISION", "f32")
         self.edge_conv = WeightedEdgeConv()
         for _ in range(unet_depth):
