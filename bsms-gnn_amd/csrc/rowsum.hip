@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_rowsum_pair_fiber(RowSumArgs a0, RowSum
     else rowsum_body<LPR, false, false, DEEP, false, false, XBF>(a0);
     return;
   }
-  __shared__ float4 red[256];
+  __shared__ float4 red[(NS + 1) * 256];
   const RowSumArgs& a = a1;
   const int ntgt = int(gridDim.x) - nsrc_blocks, j = int(blockIdx.x) - nsrc_blocks;
   constexpr int WPB = 256 / LPR;   // workers per block
@@ -266,19 +266,19 @@ __global__ __launch_bounds__(256) void k_rowsum_pair_fiber(RowSumArgs a0, RowSum
     accs.x += acc.x; accs.y += acc.y; accs.z += acc.z; accs.w += acc.w;
   }
   float* blk = part + int64_t(j) * kSmallRows * a.D;
+  // combine the workers of the workgroup in fixed order: all NS + 1 sums through LDS in ONE round (one barrier instead of
+  // 2 (NS + 1): a coarse-level launch of this kernel is nothing but its dependent round trips)
 #pragma unroll
-  for (int s = 0; s <= NS; ++s) {   // combine the workers of the workgroup in fixed order
-    red[threadIdx.x] = s < NS ? accf[s] : accs;
-    __syncthreads();
-    if (threadIdx.x < LPR) {
-      float4 v = red[threadIdx.x];
-      for (int w = 1; w < WPB; ++w) {
-        const float4 o = red[w * LPR + threadIdx.x];
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      }
-      *reinterpret_cast<float4*>(blk + (s < NS ? s : 8) * a.D + threadIdx.x * 4) = v;
+  for (int s = 0; s <= NS; ++s) red[s * 256 + threadIdx.x] = s < NS ? accf[s] : accs;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < (NS + 1) * LPR; idx += 256) {
+    const int s = idx / LPR, t = idx % LPR;
+    float4 v = red[s * 256 + t];
+    for (int w = 1; w < WPB; ++w) {
+      const float4 o = red[s * 256 + w * LPR + t];
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
-    __syncthreads();
+    *reinterpret_cast<float4*>(blk + (s < NS ? s : 8) * a.D + t * 4) = v;
   }
 }
 
