@@ -2326,6 +2326,17 @@ bool launch_edge_bwd(ChainBwdArgs& a, hipStream_t s, int& rc) {
   return true;
 }
 
+// Compute waves per workgroup of the bf16 edge chains (generic kernels, 16 rows per wave).  Round 4, same-box with the
+// experiment build (profiles/r04_bfcw.sh): 7 waves against 4 -- airfoil batch 8 bf16 222.4 -> 230.1, bf16_nodes 231.5 -> 241.5,
+// surface B=2 bf16 105.2 -> 110.9 / bf16_nodes 111.6 -> 118.0 steps/s (a workgroup streams the weights once per tile: 112 rows
+// per pass instead of 64); a launch that fits one round of 64-row tiles keeps 4 (batch 1: 614 against 597 steps/s with 7).
+template <int NB>
+int bf_edge_waves(int64_t R) {
+  static const int forced = knob("BSMS_BFEDGE_CW", 0);
+  if (forced > 0) return forced;
+  return R > int64_t(device_cus()) * resident_per_cu<NB>() * 16 * kComputeWaves ? 7 : kComputeWaves;
+}
+
 template <int NB, int IN, int OUT>
 int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   ChainFwdArgs a = a0;
@@ -2349,7 +2360,7 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
       return BSMS_OK;
     }
   }
-  const int cw = (IN == IN_EDGE) ? knob("BSMS_BFEDGE_CW", kComputeWaves) : chain_compute_waves<NB>(a.R);
+  const int cw = (IN == IN_EDGE) ? bf_edge_waves<NB>(a.R) : chain_compute_waves<NB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
   if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
   else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
@@ -2436,7 +2447,7 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
       return BSMS_OK;
     }
   }
-  const int cw = (GIN == G_EDGE_LN) ? knob("BSMS_BFEDGE_CW", kComputeWaves) : chain_compute_waves<NB>(a.R);
+  const int cw = (GIN == G_EDGE_LN) ? bf_edge_waves<NB>(a.R) : chain_compute_waves<NB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
   if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
   else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
