@@ -1789,7 +1789,7 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
 // call: same row scales, pack of the same weight scale); FIN = 0 leave raw sums, 1 un-scale, 2 un-scale + bias.
 // `rs_ext` (nullable): row scales decided by the caller (a Linear over two concatenated sources); else the row maxima of
 // `act` are taken here and noted in the running bounds (`brow`, stage index `stage`).
-template <int NB, int RB, bool SAVE, bool MASK, bool ZERO, int FIN>
+template <int NB, int RB, bool SAVE, bool MASK, bool ZERO, int FIN, bool LONE = false>
 __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, Slot& slot, int lane,
                                          float* store_base, unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB],
                                          unsigned* brow, int stage, const RowScale* rs_ext = nullptr,
@@ -1821,6 +1821,82 @@ __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act
   }
   int fw = 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (LONE) {
+    // ---- single-round launches (one workgroup per CU, one or two waves per SIMD, 256-register budget): nothing hides the
+    // chunk barrier and the LDS round trip of a chunk's first fragments (~350 of ~900 cycles per chunk, profiles/census/
+    // stage_lone.hip).  As in mfma_stage<LONE>: the wave passes the barrier of chunk c + 1 and requests its first fragments
+    // at the START of chunk c's last block pair -- whose own fragments (plane l) were requested one pair early -- so the
+    // round trip runs under six MFMAs per row block.  One barrier per chunk, in the same order; after barrier c + 1 this
+    // wave has nothing left to read of chunk c (lds_barrier waits for its LDS reads), so the loader may overwrite it.
+    static_assert(NB >= 4, "the early barrier needs two block pairs per chunk");
+    const float4* cur = nullptr;
+    const float4* body = nullptr;
+    float4 f0, f1;
+#pragma unroll
+    for (int c = 0; c < Rg::NCH; ++c) {
+      if (c == 0) {
+        lds_barrier();
+        cur = lds + slot.i * Rg::CH4;
+        if (++slot.i == slot.nr) slot.i = 0;
+        body = cur + kChunkHdrFloats / 4 + lane;
+        f0 = body[0]; f1 = body[2 * 64];
+        fw = int(__float_as_uint(reinterpret_cast<const float*>(cur)[kScaleSlot]) >> 23);
+      }
+      const int cb = c & 1;
+      int islot = 0;
+      auto pair = [&](int t, int rb, const float4& a0, const float4& a1, const unsigned (&piece)[4], bool first) {
+        acc[rb][t] = mma(a0, vec4(piece), (ZERO && first && c == 0) ? zero : acc[rb][t]);
+        acc[rb][t + 1] = mma(a1, vec4(piece), (ZERO && first && c == 0) ? zero : acc[rb][t + 1]);
+        const int s = (islot * NSTEP + NSLOT - 1) / NSLOT;
+        if (s < NSTEP && s * NSLOT / NSTEP == islot)
+          valu_step<NB, RB, SAVE, MASK>(s, c, act, pc, st, rs, mword, store_base, bits_base, off, moff, lane);
+        ++islot;
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      float4 m0 = f0, m1 = f1;   // plane l of the LAST block pair, requested one pair early
+      float4 g0 = f0, g1 = f1;   // first fragments of the NEXT chunk
+      const float4* ncur = cur;
+      const float4* nbody = body;
+#pragma unroll
+      for (int t = 0; t < NB; t += 2) {
+        float4 n0, n1;
+        if (t == NB - 2) {
+          n0 = m0; n1 = m1;
+          if (c + 1 < Rg::NCH) {   // every read of this chunk has been issued: barrier of the next one, its first fragments
+            lds_barrier();
+            ncur = lds + slot.i * Rg::CH4;
+            if (++slot.i == slot.nr) slot.i = 0;
+            nbody = ncur + kChunkHdrFloats / 4 + lane;
+            g0 = nbody[0]; g1 = nbody[2 * 64];
+          }
+        } else {
+          n0 = body[(t * 2 + 1) * 64]; n1 = body[(t * 2 + 3) * 64];
+          if (t == NB - 4) { m0 = body[((NB - 2) * 2 + 1) * 64]; m1 = body[((NB - 2) * 2 + 3) * 64]; }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].l, true);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h, false);
+        f0 = n0;
+        f1 = n1;
+        if (t + 2 < NB) {
+          n0 = body[((t + 2) * 2) * 64];
+          n1 = body[((t + 2) * 2 + 2) * 64];
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) pair(t, rb, f0, f1, pc[rb][cb].h, false);
+        f0 = n0;
+        f1 = n1;
+      }
+      if (FIN != 0 && c == Rg::NCH - 1) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) finish_stage<NB, FIN == 2>(acc[rb], rs[rb].E, fw, reinterpret_cast<const float*>(cur), lane);
+      }
+      cur = ncur; body = nbody; f0 = g0; f1 = g1;
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < Rg::NCH; ++c) {
 #ifdef BSMS_EXPERIMENTS
@@ -1892,8 +1968,9 @@ struct EdgeTile {
   static constexpr int resident = (NB * RB <= 8) ? 2 : 1;       // workgroups per CU (see resident_per_cu)
 };
 
-template <int NB, int RB, bool SAVE>
-__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(EdgeTile<NB, RB>::waves_per_eu)))
+// LONE: the instantiation for launches of at most one workgroup per CU (stage_rb<.., LONE>; 256-register budget)
+template <int NB, int RB, bool SAVE, bool LONE = false>
+__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(LONE ? 2 : EdgeTile<NB, RB>::waves_per_eu)))
 void k_edge_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -1997,9 +2074,9 @@ void k_edge_fwd(ChainFwdArgs a) {
       float* st_tile = SAVE ? pending + int64_t(tile) * (tile_rows * D) : nullptr;   // uniform
       unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (tile_rows * 4 * mask_words<NB>()) : nullptr;
 #ifdef BSMS_EXPERIMENTS
-      stage_rb<NB, RB, SAVE, true, true, 2>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l, nullptr, a.timing ? &waited : nullptr);
+      stage_rb<NB, RB, SAVE, true, true, 2, LONE>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l, nullptr, a.timing ? &waited : nullptr);
 #else
-      stage_rb<NB, RB, SAVE, true, true, 2>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
+      stage_rb<NB, RB, SAVE, true, true, 2, LONE>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
 #endif
       stamp();
       if (l + 1 < a.nstage) {
@@ -2039,8 +2116,8 @@ void k_edge_fwd(ChainFwdArgs a) {
   if (SAVE) flush_bounds(a.amax, kMaxStages + 1, brow, wave, lane);
 }
 
-template <int NB, int RB>
-__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(EdgeTile<NB, RB>::waves_per_eu)))
+template <int NB, int RB, bool LONE = false>
+__global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(LONE ? 2 : EdgeTile<NB, RB>::waves_per_eu)))
 void k_edge_bwd(ChainBwdArgs a) {
   constexpr int D = NB * 16, W = mask_words<NB>();
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -2105,7 +2182,7 @@ void k_edge_bwd(ChainBwdArgs a) {
 #pragma unroll
         for (int w = 0; w < W; ++w)
           mbits[rb][w] = reinterpret_cast<const unsigned*>(a.mask[k] + pad_rows(a.R) * D)[rowc[rb] * (4 * W) + lg * W + w];
-      stage_rb<NB, RB, true, false, true, 1>(acc, g, ring, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff, brow, k);
+      stage_rb<NB, RB, true, false, true, 1, LONE>(acc, g, ring, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff, brow, k);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -2275,6 +2352,15 @@ int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
   pick_stream<NB>(a.ntiles, cw, edge_loader_waves<NB>(), a.nload, a.nring);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
+  static const int lone = knob("BSMS_EDGE_LONE", 1);
+  if (lone && a.ntiles <= device_cus() && !a.timing) {   // one round of workgroups: the variant that passes the chunk barrier early (stage_rb<LONE>)
+    static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+    BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve LDS (single-round build)");
+    hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE, true>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes(a.nring), s, a);
+    BSMS_LAUNCH_CHECK();
+    return BSMS_OK;
+  }
   hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes(a.nring), s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
@@ -2309,6 +2395,15 @@ int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
   pick_stream<NB>(a.ntiles, cw, edge_loader_waves<NB>(), a.nload, a.nring);
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
+  static const int lone = knob("BSMS_EDGE_LONE", 1);
+  if (lone && a.ntiles <= device_cus()) {   // see launch_edge_fwd_t
+    static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+    BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve LDS (single-round build)");
+    hipLaunchKernelGGL((k_edge_bwd<NB, RB, true>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes(a.nring), s, a);
+    BSMS_LAUNCH_CHECK();
+    return BSMS_OK;
+  }
   hipLaunchKernelGGL((k_edge_bwd<NB, RB>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes(a.nring), s, a);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
