@@ -363,6 +363,84 @@ def rollout_rate(sim, wl, steps=200):
     return out
 
 
+def timed_steps(step, warmup, steps):
+    """steps/s of `step()` over a short region: `warmup` untimed steps, then `steps` steps between two synchronisations."""
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return steps / dt, dt / steps * 1e3, float(loss.detach())
+
+
+def other_lines(sim_airfoil, data_airfoil, loss_f32, warmup=10, steps=30):
+    """The other BASELINE configurations on the driver's line (N = 1, default run only): each its own short timed region
+    (10 warm-up + 30 steps, wall clock between two synchronisations), same step definition as `value`.
+      airfoil_bf16 / airfoil_bf16_nodes   BASELINE configs[2]: the headline workload in the BSMS_BF16 / BSMS_BF16_NODES precision
+      surface_b2_bf16                      configs[4] per GPU: 16384 nodes, 6 levels, D=256, pos_dim 3, batch 2
+      cylinder_b8 / cylinder_b8_blockdiag  configs[1]: dense batch of one mesh / 8 different meshes in one block-diagonal batch
+    `loss_vs_f32` = |loss - fp32 loss| / fp32 loss of the SAME engine, model and batch; `loss_vs_oracle` (cylinder, dense) =
+    against the CPU oracle's forward on the same seed."""
+    import gc
+    import bsms_gnn_amd as eng
+    out = {"protocol": f"{warmup} warm-up + {steps} timed steps per line, wall clock between two synchronisations; N = 1"}
+
+    def run(sim, data, consistent, dtype):
+        sim.process.precision = dtype
+        dp = eng.DataParallel(sim)
+        v, ms, loss = timed_steps(lambda: dp.step_loss_backward(data, consistent), warmup, steps)
+        return {"value": v, "unit": "steps/s", "ms_per_step": ms, "steps": steps, "dtype": dtype, "loss": loss}
+
+    for dtype in ("bf16", "bf16_nodes"):
+        r = run(sim_airfoil, data_airfoil, True, dtype)
+        r["loss_vs_f32"] = abs(r["loss"] - loss_f32) / abs(loss_f32)
+        out[f"airfoil_{dtype}"] = r
+    sim_airfoil.process.precision = "f32"
+    gc.collect(); torch.cuda.empty_cache()
+
+    def fresh(kind, batch, blockdiag=False):
+        wl = build_workload(kind, batch, "cuda")
+        torch.manual_seed(0)
+        sim = eng.BSMS_Simulator(make_cfg(wl["cfg"])).cuda()
+        if blockdiag:
+            data, consistent = build_blockdiag_workload(kind, batch, "cuda")["data"], False
+        else:
+            data, consistent = data_tuple(wl), True
+        sim(data, consistent, True)
+        return wl, sim, data, consistent
+
+    wl, sim, data, consistent = fresh("surface", 2)
+    f32 = run(sim, data, consistent, "f32")
+    r = run(sim, data, consistent, "bf16")
+    r["loss_vs_f32"] = abs(r["loss"] - f32["loss"]) / abs(f32["loss"])
+    out["surface_b2_bf16"], out["surface_b2_f32"] = r, f32
+    del sim, data, wl
+    gc.collect(); torch.cuda.empty_cache()
+
+    wl, sim, data, consistent = fresh("cylinder", 8)
+    r = run(sim, data, consistent, "f32")
+    try:   # the CPU oracle's forward on the same seed and batch (no backward: ~1 s)
+        from oracle import bsms_oracle as ro
+        wc = build_workload("cylinder", 8, "cpu")
+        torch.manual_seed(0)
+        ref = ro.BSMS_Simulator(make_cfg(wc["cfg"]))
+        ref(data_tuple(wc), True, True)
+        with torch.no_grad():
+            lo = float(ro.masked_rmse(ref(data_tuple(wc), True, False), wc["target"], wc["mask"]))
+        r["loss_vs_oracle"] = abs(r["loss"] - lo) / abs(lo)
+    except Exception as e:  # noqa: BLE001  (the line is still worth printing)
+        r["loss_vs_oracle"] = f"not computed: {e}"
+    out["cylinder_b8"] = r
+    del sim, data
+    gc.collect(); torch.cuda.empty_cache()
+    wl, sim, data, consistent = fresh("cylinder", 8, blockdiag=True)
+    out["cylinder_b8_blockdiag"] = run(sim, data, consistent, "f32")
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
@@ -425,6 +503,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the kernel micro-loops (for rocprofv3 --pmc passes)")
+    ap.add_argument("--no-other-lines", action="store_true", help="skip the short timed regions of the other BASELINE configurations")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -502,10 +581,24 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]) if args.steps else np.zeros(1)
+    allreduce_us = None
     if world > 1:
-        t = torch.tensor([elapsed, float(np.median(per_step))], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, float(np.median(per_step)), host_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, med_ms = float(t[0]), float(t[1])
+        elapsed, med_ms, host_ms = float(t[0]), float(t[1]), float(t[2])   # host enqueue: the slowest rank's
+        # the gradient message on its own: 20 back-to-back all-reduces of the flat gradient buffer inside one HIP event pair
+        for _ in range(3):
+            dist.all_reduce(dp.grads.flat)
+        torch.cuda.synchronize()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(20):
+            dist.all_reduce(dp.grads.flat)
+        eb.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([ea.elapsed_time(eb) / 20 * 1e3], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_us = float(t[0])
     else:
         med_ms = float(np.median(per_step))
 
@@ -541,6 +634,8 @@ def main():
             line["distributed"] = {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                                    "gradient_allreduce": ("per bucket under the backward" if probe and probe.get("use") else "one message after the backward"),
                                    "allreduce_self_check_ms": None if not probe else probe.get("measured_ms"),
+                                   "gradient_allreduce_us": allreduce_us, "gradient_bytes": int(dp.grads.flat.numel()) * 4,
+                                   "host_enqueue_ms_per_step_max_over_ranks": host_ms,
                                    "launcher": os.environ.get("BSMS_BENCH_LAUNCHER", "torch.distributed.run"),
                                    "devices": torch.cuda.device_count(),
                                    "note": None if backend == "nccl" else
@@ -550,6 +645,8 @@ def main():
             line["rollout"] = rollout_rate(sim, wl)
         if world == 1:
             line["optimizer_step"] = optimizer_step_time(dp)
+        if world == 1 and consistent and args.workload == "airfoil" and args.dtype == "f32" and args.batch == 8 and not args.no_other_lines:
+            line["other_lines"] = other_lines(sim, data, line["config"]["loss"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cb = cpu_baseline(args.workload, args.batch)
             if consistent:   # same seed, same workload: the oracle's loss IS the expected GPU loss (parity at bench size)

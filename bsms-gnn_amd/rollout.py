@@ -99,8 +99,10 @@ def rollout_batch(trainer, IC, results, node_mask, m_gs, m_ids, use_graph=False,
                            results.shape[-1], use_graph and IC.is_cuda)
         for ti in range(results.shape[0]):
             results[ti, lo:hi] = stepper.step()
-    if shard and gather and (lo, hi) != (0, B):
-        import torch.distributed as dist
+    # rank-independent condition: every rank of the group must enter the collective or none (with B < world a rank's
+    # slice can be the whole batch while another's is empty -- deciding from (lo, hi) deadlocked the others)
+    import torch.distributed as dist
+    if shard and gather and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         w = dist.get_world_size(group)
         width = -(-B // w)                                   # equal-size pieces for all_gather; the tail piece is padded
         mine = results.new_zeros(results.shape[0], width, *results.shape[2:])
@@ -124,13 +126,23 @@ def rollout_errors(results, target, node_mask):
       rmse   [1,1]     sqrt(sum(se * mask) / sum(mask) / C) over all time steps, nodes and channels
       rmse_c [T-1,C]   sqrt(sum_nodes(se * mask) / sum_nodes(mask)) per time step and channel
       rmse_t [C,T-1]   its transpose (what the per-time accumulator is fed)"""
+    if node_mask.dim() != 3 or node_mask.shape[0] != results.shape[0] or results.dim() != 3:
+        raise ValueError(f"rollout_errors: results / target [T-1,N,C] and node_mask [T-1,N,1] expected, got "
+                         f"{tuple(results.shape)} and {tuple(node_mask.shape)} (a [N,1] mask must be repeated over time, "
+                         "as the reference's rollout datapipe does)")
     se = (results - target) ** 2
     rmse = torch.sqrt((se * node_mask).sum() / node_mask.sum() / se.shape[-1])
     rmse_c = torch.sqrt((se * node_mask).sum(dim=1) / node_mask.sum(dim=1))
     return rmse.unsqueeze(0).unsqueeze(0), rmse_c, rmse_c.detach().clone().T
 
 
-rollout_rmse = rollout_errors      # the name rounds 1-3 exported (their version averaged differently from the reference)
+def rollout_rmse(results, target, node_mask):
+    """Deprecated name of rounds 1-3 (it pooled over time, which is NOT what the reference accumulates): forwards to
+    `rollout_errors` -- note the [T-1,N,1] mask and the three return values -- and says so."""
+    import warnings
+    warnings.warn("rollout_rmse is deprecated: use rollout_errors (mask [T-1,N,1]; returns rmse [1,1], rmse_c [T-1,C], rmse_t [C,T-1])",
+                  DeprecationWarning, stacklevel=2)
+    return rollout_errors(results, target, node_mask)
 
 
 class RolloutErrors:

@@ -35,6 +35,13 @@ def test_every_declared_symbol_is_exported_and_bound(eng):
         assert hasattr(lib, n), f"{n} declared in bsms_hip.h but not exported"
     assert set(names) == set(_abi.SIGNATURES), set(names) ^ set(_abi.SIGNATURES)
     assert _abi.lib().bsms_abi_version() >= 1
+    # ... and the converse: the production library exports no C-ABI entry the header does not declare (experiment-only
+    # entries such as bsms_debug_* exist in -DBSMS_EXPERIMENTS builds only)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("bsms_") and ln.split()[-2] in ("T", "t", "W")}
+    assert exported, "nm found no bsms_* entry points"
+    assert exported <= set(names), f"exported but not declared in include/bsms_hip.h: {sorted(exported - set(names))}"
 
 
 def test_size_queries_and_validation_without_gpu(eng):

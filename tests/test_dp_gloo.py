@@ -134,3 +134,81 @@ def test_bucket_schedule_follows_the_backward_execution_order():
         want = max(0 if n.startswith("decode.") else next(i for i, pre in enumerate(exec_order) if n.startswith(pre + ".")) for n in names)
         assert e == want, (names[0], e, want)
     assert sched[0] is not None and sched[-1] is None          # the decoder's bucket goes first, the encoder's last
+
+
+class _Recorder:
+    """Stand-in for torch.distributed inside step.FusedStep._backward_overlapped: records the collectives in issue order."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    class _Work:
+        def wait(self):
+            pass
+
+    def __init__(self):
+        self.calls = []
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        self.calls.append((t.data_ptr(), t.numel()))
+        return self._Work()
+
+
+@pytest.mark.parametrize("depth", [4, 5, 6])
+def test_overlapped_allreduce_issue_order_is_rank_independent(depth, monkeypatch):
+    """the scheduling of the per-bucket gradient all-reduce (step.FusedStep) with a fake
+    process group that records the call order -- two 'ranks' (same architecture, different weights) issue the same
+    collectives in the same order, every bucket exactly once, event-released buckets in non-decreasing event order
+    (= the order the backward completes them) and the join-released ones last.  No GPU: the backward itself is stubbed."""
+    import bsms_gnn_amd as eng
+    import bsms_gnn_amd.dp as dp
+    import bsms_gnn_amd.step as step
+    from oracle import bsms_oracle as ro
+
+    class _Ev:
+        cuda_event = 0
+        def record(self):
+            pass
+
+    class _Stream:
+        def __init__(self, device=None):
+            pass
+        def wait_event(self, e):
+            pass
+        def wait_stream(self, s):
+            pass
+
+    class _Ctx:
+        def __init__(self, s):
+            pass
+        def __enter__(self):
+            return self
+        def __exit__(self, *a):
+            return False
+
+    orders = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        sim = eng.BSMS_Simulator(ro.make_cfg(3, 128, 3, depth, 2))
+        grads = dp.GradBuckets(list(sim.parameters()), 2 << 20, None)
+        fs = step.FusedStep(sim, grads)
+        rec = _Recorder()
+        monkeypatch.setattr(step, "dist", rec)
+        monkeypatch.setattr(step.torch.cuda, "Event", _Ev)
+        monkeypatch.setattr(step.torch.cuda, "Stream", _Stream)
+        monkeypatch.setattr(step.torch.cuda, "stream", _Ctx)
+        monkeypatch.setattr(step.torch.cuda, "current_stream", lambda: _Stream())
+        monkeypatch.setattr(step._abi, "ptr_array", lambda ps: (ps, None))
+        monkeypatch.setattr(fs, "_backward", lambda *a, **k: None)
+        fs._backward_overlapped(dict(depth=depth, h0=torch.zeros(1)), None, None, None, 8, 100)
+        sched = fs._overlap["sched"]
+        assert len(sched) == len(grads.buckets) >= 3
+        ev = [e for e in sched if e is not None]
+        assert ev == sorted(ev) and all(0 <= e <= 2 * depth for e in ev)           # buckets complete in backward order
+        assert sched[-1] is None or sched[-1] == 2 * depth                           # the encoder's bucket: only the final join
+        base = grads.flat.data_ptr()
+        order = [((ptr - base) // 4, n) for ptr, n in rec.calls]
+        assert sorted(order) == sorted(((bk["view"].data_ptr() - base) // 4, bk["view"].numel()) for bk in grads.buckets)   # each bucket once
+        assert [k for k, e in fs._issue_order(sched)] == [k for k, e in enumerate(sched) if e is not None] + [k for k, e in enumerate(sched) if e is None]
+        orders.append(order)
+    assert orders[0] == orders[1]

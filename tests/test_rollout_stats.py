@@ -43,7 +43,6 @@ def test_product_error_statistics_match_the_reference():
     summ = errs.summary()
     for name in ("all", "channel", "time"):
         assert torch.equal(summ[name][0], z.t(f"{name}/mean")) and torch.equal(summ[name][1], z.t(f"{name}/std")), name
-    assert eng.rollout_rmse is eng.rollout_errors
     # per-channel = mean over time of the per-(time, channel) RMSE -- NOT the RMSE pooled over time (what rounds 1-3 computed)
     res, tar, mask = _trajs(z)[0]
     pooled = torch.sqrt((((res - tar) ** 2) * mask).sum(dim=(0, 1)) / mask.sum())
@@ -101,3 +100,58 @@ def test_sharded_rollout_statistics_equal_single_process(tmp_path, world):
         assert sl[0][0] == 0 and sl[-1][1] == m and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
         sizes = [hi - lo for lo, hi in sl]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _gather_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import bsms_gnn_amd as eng
+    from conftest import Golden
+    from oracle import bsms_oracle as ro
+    graphs = Golden("graphs")
+    es, ids = graphs.levels("del64")
+    n, C, T = 64, 2, 3
+    torch.manual_seed(0)
+    model = ro.BSMS_Simulator(ro.make_cfg(C, 16, 2, 2, 2))
+    pos = torch.tensor(graphs.np("del64/pos"), dtype=torch.float32)
+    res = {}
+    for B in (1, 2, 4):                                   # B < world, B == world - 1, B > world
+        gen = torch.Generator().manual_seed(B)
+        ic = torch.cat([torch.randn(B, n, C, generator=gen), pos.expand(B, n, 2), torch.zeros(B, n, 1)], -1)
+        mask = torch.ones(B, n, 1)
+        gs = [e.unsqueeze(0).repeat(B, 1, 1) for e in es[:3]]
+        iis = [i.unsqueeze(0).repeat(B, 1) for i in ids[:2]]
+        model((ic, ic[..., :C], mask, gs, iis), True, True)   # normaliser statistics (same on every rank)
+        full = eng.rollout_batch(model, ic, torch.zeros(T, B, n, C), mask, gs, iis)                 # every trajectory on this rank
+        got = eng.rollout_batch(model, ic, torch.zeros(T, B, n, C), mask, gs, iis, shard=True, gather=True)
+        res[B] = (full, got)
+    torch.save(res, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_rollout_gather_with_fewer_trajectories_than_ranks(tmp_path):
+    """`rollout_batch(shard=True, gather=True)` with B < world -- rank 0's slice is the whole batch, the
+    others' slices are empty; every rank must still enter the all_gather (the old per-rank guard deadlocked) and every
+    rank must return all frames."""
+    world = 3
+    port = 29990 + os.getpid() % 40
+    out = str(tmp_path / "g")
+    mp.start_processes(_gather_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
+    for r in range(world):
+        res = torch.load(f"{out}.{r}")
+        for B, (full, got) in res.items():
+            assert torch.equal(full, got), (r, B)
+
+
+def test_rollout_errors_rejects_an_unrepeated_mask():
+    import bsms_gnn_amd as eng
+    res, tar = torch.randn(4, 10, 2), torch.randn(4, 10, 2)
+    with pytest.raises(ValueError):
+        eng.rollout_errors(res, tar, torch.ones(10, 1))
+    with pytest.warns(DeprecationWarning):
+        eng.rollout_rmse(res, tar, torch.ones(4, 10, 1))
