@@ -219,6 +219,32 @@ size_t small_wgrad_work_bytes(int D);
 size_t small_wgrad_work_bytes_rows(int D, int64_t workers);   // sized for the fused pair kernel: one block per 256 / (D/4) row workers
 int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s);
 
+// efuse.hip: the fused backward of the edge MLP in the bf16 precisions (D = 128, hidden = 3): forward recompute + LayerNorm
+// backward + dgrad chain + the weight / bias gradients of Linears 1..3 accumulated on chip; g_0 leaves as bf16
+struct EdgeFusedBwdArgs {
+  int64_t R;                  // B * E edge rows (plan order)
+  int32_t E, N;
+  const int32_t *src, *dst;   // plan-order endpoints
+  const float *Ps, *Pd;       // the forward's node projections [B*N, D] (kept in the saved blob in this mode)
+  const float* fiber;         // [R, 4]: the fiber rows the forward kept
+  const float* wft;           // fiber weights^T [p+1][D]
+  int p;
+  const float* W[3];          // fp32 weights of edge Linears 1..3, [D][D] row-major (rounded to bf16 as the forward's packs are)
+  const float* b[3];          // their biases
+  const float* dy;            // [B*N, D] gradient of the aggregate (gathered by target)
+  const void* y;              // [R, D] bf16 messages
+  const float* rstd;          // [R]
+  void* g0;                   // [pad_rows(R), D] bf16: gradient w.r.t. the first edge Linear's output
+  float* gmax;                // bound slot of g0 (kBoundWidth floats), nullable
+  float* part;                // per-workgroup partials, edge_fused_part_floats() floats
+  int ntiles;                 // filled by the launcher
+};
+constexpr int kEdgeFusedMaxWg = 256;
+bool edge_fused_supported(int64_t D, int H, int64_t p, int precision);
+size_t edge_fused_part_floats();
+int launch_edge_fused_bwd(EdgeFusedBwdArgs a, int* nwg_out, hipStream_t s);
+int launch_edge_fused_reduce(const float* part, int nwg, float* const dW[3], float* const db[3], hipStream_t s);
+
 // from rowsum.hip
 int rowsum_plan_order(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
 int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);

@@ -59,6 +59,7 @@ void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, i
 // ================================================================================== GMP layout
 struct GmpSaved {
   float *e_act[kMaxStages], *e_y, *e_rstd, *aggr, *e_fiber;
+  float *e_Ps, *e_Pd;   // fused edge backward (efuse.hip): the two node projections are kept for the backward's recompute
   float *n_act[kMaxStages], *n_yln, *n_rstd;
   // packs (fragment order)
   float *e_wi, *e_wj, *e_wft, *e_w[kMaxStages], *e_wt[kMaxStages], *e_wit, *e_wjt;
@@ -75,14 +76,16 @@ struct GmpSaved {
 // they can be filled ahead of the call and survive the scratch reuse of other blocks.
 // `bf`: bf16 precision -- the edge activations and the messages are bf16 (half the floats; the sign bits keep their size);
 // `bfn` (BSMS_BF16_NODES): the node MLP's saved activations likewise
+// `fused` (use_edge_fused): the edge backward recomputes its activations (efuse.hip): no e_act tensors, the projections instead
 GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H, bool training = true,
-                         void* packs_base = nullptr, bool bf = false, bool bfn = false) {
+                         void* packs_base = nullptr, bool bf = false, bool bfn = false, bool fused = false) {
   Carver c(base);
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
   const size_t edge_act = bf ? pad_rows(re) * (size_t(D) / 2 + mask_words_per_row(D)) : act_floats(re, D);
-  if (training)
+  if (training && !fused)
     for (int l = 0; l < H; ++l) s.e_act[l] = c.take(edge_act);
+  if (training && fused) { s.e_Ps = c.take(rn * D); s.e_Pd = c.take(rn * D); }
   s.e_y = c.take(bf ? re * D / 2 : re * D);
   if (training) s.e_rstd = c.take(re);
   if (training) s.e_fiber = c.take(re * 8);   // [B*E, fiber_ld(p)]: sized for the widest pitch (p is not part of the size query)
@@ -111,6 +114,7 @@ struct GmpWork {
   float *gE[kMaxStages + 1], *dPs, *dPd;
   char *wg, *wg2, *sw;
   size_t sw_bytes;
+  float* ef_part;   // fused edge backward: per-workgroup partial weight gradients (efuse.hip)
   size_t bytes;
 };
 GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H) {
@@ -126,9 +130,19 @@ GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, i
   w.wg2 = c.take_bytes(wgrad_work_bytes((int)D, 0));   // second split-K area: two wgrad launches run concurrently
   w.sw_bytes = small_wgrad_work_bytes_rows((int)D, B * N);   // one partial block per workgroup of the fused scatter kernel
   w.sw = c.take_bytes(w.sw_bytes);
+  w.ef_part = (D == 128 && H == 3) ? c.take(edge_fused_part_floats()) : nullptr;
   w.bytes = c.off;
   return w;
 }
+// The fused edge backward (efuse.hip) is THE path of the bf16 precisions at D = 128, hidden = 3; experiment builds can switch
+// it off for A/B runs (BSMS_EDGE_FUSED=0).  A pure function of the shape: size queries and calls agree.
+#ifdef BSMS_EXPERIMENTS
+static int env_fused() { const char* e = getenv("BSMS_EDGE_FUSED"); return e ? atoi(e) : 1; }
+static const int g_edge_fused = env_fused();
+#else
+constexpr int g_edge_fused = 1;
+#endif
+bool use_edge_fused(int64_t D, int H, int precision) { return g_edge_fused && edge_fused_supported(D, H, 1, precision); }
 
 int check_gmp(const bsms_plan_t* plan, int64_t B, int64_t D, int64_t p, int H, const char* who) {
   BSMS_REQUIRE(plan != nullptr, BSMS_E_INVALID_ARG, "%s: plan is null", who);
@@ -161,7 +175,7 @@ namespace {
 // where the saved tensors / packs of a forward call live (see carve_gmp_saved)
 GmpSaved locate_saved(void* saved, const GmpWork& wk, int64_t B, int64_t N, int64_t E, int64_t D, int H, void* packs_base,
                       bool bf = false, bool bfn = false) {
-  return saved ? carve_gmp_saved(saved, B, N, E, D, H, true, nullptr, bf, bfn)
+  return saved ? carve_gmp_saved(saved, B, N, E, D, H, true, nullptr, bf, bfn, use_edge_fused(D, H, bf ? (bfn ? BSMS_BF16_NODES : BSMS_BF16) : BSMS_F32))
                : carve_gmp_saved(wk.gN[0], B, N, E, D, H, false, packs_base, bf, bfn);  // inference: lives in the gradient scratch
 }
 
@@ -221,7 +235,8 @@ int bsms::gmp_prepack(int64_t B, int64_t N, int64_t E, int64_t D, int64_t p, int
 }
 size_t bsms::gmp_saved_bytes_p(int64_t B, int64_t N, int64_t E, int64_t D, int hidden, int precision) {
   if (hidden < 1 || hidden >= kMaxStages) return 0;
-  return carve_gmp_saved(nullptr, B, N, E, D, hidden, true, nullptr, precision != BSMS_F32, precision == BSMS_BF16_NODES).bytes;
+  return carve_gmp_saved(nullptr, B, N, E, D, hidden, true, nullptr, precision != BSMS_F32, precision == BSMS_BF16_NODES,
+                         use_edge_fused(D, hidden, precision)).bytes;
 }
 
 extern "C" int bsms_gmp_fwd(const bsms_plan_t* plan, const float* x, const float* pos, int64_t B, int64_t D, int64_t p,
@@ -244,27 +259,30 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
   GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, bf, bfn);
   if (do_prepack && (rc = prepack_block(sv, D, p, H, training, params, s, bf, bfn))) return rc;
+  const bool fused = training && use_edge_fused(D, H, precision);   // the backward recomputes the edge activations (efuse.hip)
+  float* const Ps = fused ? sv.e_Ps : wk.Ps;
+  float* const Pd = fused ? sv.e_Pd : wk.Pd;
 
   // node pre-projections
   {
     ChainFwdArgs a{};
     a.R = B * N; a.x = x; a.nstage = 2;   // both projections in one launch (OUT_PLAIN2); bias b0 rides in the first pack
-    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wi); a.y = wk.Ps;
-    a.wp[1] = reinterpret_cast<const float4*>(sv.e_wj); a.y2 = wk.Pd;
+    a.wp[0] = reinterpret_cast<const float4*>(sv.e_wi); a.y = Ps;
+    a.wp[1] = reinterpret_cast<const float4*>(sv.e_wj); a.y2 = Pd;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN2, a, s))) return rc;
   }
   // edge MLP + LayerNorm
   {
     ChainFwdArgs a{};
-    a.R = B * E; a.K0 = int(p + 1); a.w0t = sv.e_wft; a.store_in = sv.e_act[0];
+    a.R = B * E; a.K0 = int(p + 1); a.w0t = sv.e_wft; a.store_in = fused ? nullptr : sv.e_act[0];
     a.src = plan->src; a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
-    a.Ps = wk.Ps; a.Pd = wk.Pd; a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p;
+    a.Ps = Ps; a.Pd = Pd; a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p;
     a.fiber_out = training ? sv.e_fiber : nullptr;
     a.bf16 = bf;
     a.nstage = H;
     for (int st = 0; st < H; ++st) {
       a.wp[st] = reinterpret_cast<const float4*>(sv.e_w[st + 1]);
-      a.store[st] = (training && st < H - 1) ? sv.e_act[st + 1] : nullptr;
+      a.store[st] = (training && !fused && st < H - 1) ? sv.e_act[st + 1] : nullptr;
     }
     a.y = sv.e_y; a.rstd = sv.e_rstd;
     if (training && !bf) for (int st = 0; st < H; ++st) a.amax[st] = sv.bound + size_t(st) * kBoundWidth;
@@ -343,8 +361,10 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   float* const* gn = grads;
   float* const* ge = grads + 2 * nl;
   const int ldE0 = int(2 * D + p + 1);
-  GmpSaved sv = carve_gmp_saved(const_cast<void*>(saved), B, N, E, D, H, true, nullptr, bf, bfn);
+  const bool fused = use_edge_fused(D, H, precision);
+  GmpSaved sv = carve_gmp_saved(const_cast<void*>(saved), B, N, E, D, H, true, nullptr, bf, bfn, fused);
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
+  int ef_nwg = 0;
 
   // node MLP backward: grad_x = grad_out (residual) + g0 W0x ; daggr = g0 W0a
   {
@@ -366,7 +386,17 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     if ((rc = launch_chain_bwd((int)D, G_ROWS_LN, F_HEADS2, a, s))) return rc;
   }
   // edge MLP backward (gradient of the aggregation = gather by target)
-  {
+  if (fused) {   // recompute + LayerNorm backward + dgrad + the weight gradients of Linears 1..H on chip (efuse.hip)
+    EdgeFusedBwdArgs a{};
+    a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
+    a.Ps = sv.e_Ps; a.Pd = sv.e_Pd; a.fiber = sv.e_fiber; a.wft = sv.e_wft; a.p = (int)p;
+    const float* const* pe = params + 2 * nl;
+    for (int l = 1; l <= 3; ++l) { a.W[l - 1] = pe[2 * l]; a.b[l - 1] = pe[2 * l + 1]; }
+    a.dy = wk.daggr; a.y = sv.e_y; a.rstd = sv.e_rstd; a.g0 = wk.gE[0];
+    a.gmax = sv.bound + size_t(16 + H) * kBoundWidth;
+    a.part = wk.ef_part;
+    if ((rc = launch_edge_fused_bwd(a, &ef_nwg, s))) return rc;
+  } else {
     ChainBwdArgs a{};
     a.R = B * E; a.dy = wk.daggr; a.yln = sv.e_y; a.rstd = sv.e_rstd; a.store_mode = ((g_debug_flags & 2) ? 0 : (g_debug_flags & 256) ? 2 : 1) | ((g_debug_flags & 128) ? 8 : 0);
     a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;
@@ -408,7 +438,12 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       j.g_bound = gb; j.a_bound = ab; j.g_mul = j.a_mul = 1.f;
     };
     auto bd = [&](int slot) { return sv.bound + size_t(slot) * kBoundWidth; };
-    for (int l = 1; l <= H; ++l) {   // edge Linears: bf16 gradient and activation tensors in the bf16 precision
+    if (fused) {   // the edge Linears' gradients were accumulated by the fused kernel: only the fixed-order sum of its partials is left
+      float* const dWs[3] = {ge[2], ge[4], ge[6]};
+      float* const dbs[3] = {ge[3], ge[5], ge[7]};
+      if ((rc = launch_edge_fused_reduce(wk.ef_part, ef_nwg, dWs, dbs, ws))) return rc;
+    }
+    for (int l = 1; l <= H && !fused; ++l) {   // edge Linears: bf16 gradient and activation tensors in the bf16 precision
       add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0, bd(16 + (H - l)), bd(l - 1));
       jobs[nj - 1].bf16 = bf;
     }
