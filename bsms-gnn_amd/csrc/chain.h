@@ -238,6 +238,7 @@ struct EdgeFusedBwdArgs {
   float* gmax;                // bound slot of g0 (kBoundWidth floats), nullable
   float* part;                // per-workgroup partials, edge_fused_part_floats() floats
   int ntiles;                 // filled by the launcher
+  unsigned long long* timing; // experiments only: phase stamps (null in production)
 };
 constexpr int kEdgeFusedMaxWg = 256;
 bool edge_fused_supported(int64_t D, int H, int64_t p, int precision);

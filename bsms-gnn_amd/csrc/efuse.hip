@@ -171,6 +171,20 @@ __device__ __forceinline__ void load_rows(f32x4 (&v)[NBX], const float* row, int
   for (int t = 0; t < NBX; ++t) v[t] = *reinterpret_cast<const f32x4*>(row + 16 * t + 4 * g);
 }
 
+// experiments (profiles/ef_timeline.py): phase stamps of chain wave 0 / gradient wave 4, 16 + 16 slots per tile
+#ifdef BSMS_EXPERIMENTS
+#define EF_STAMP(slot)                                                                                          \
+  do {                                                                                                           \
+    if (a.timing && lane == 0 && (wave == 0 || wave == 4)) {                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                         \
+      a.timing[size_t(int(blockIdx.x) + it * int(gridDim.x)) * 32 + (wave == 4 ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memtime(); \
+      __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }                                                                                                            \
+  } while (0)
+#else
+#define EF_STAMP(slot) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_fused_bwd(EdgeFusedBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -214,8 +228,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int it = 0; it < my_tiles; ++it) {
 #pragma unroll
       for (int l = 2; l >= 0; --l) {
+        EF_STAMP(4 * (2 - l));
         lds_barrier();   // X: the chain waves may overwrite the staging tiles (everybody is done with the previous pair)
+        EF_STAMP(4 * (2 - l) + 1);
         lds_barrier();   // Y: (G_{l+1}, A_l) of this tile are staged
+        EF_STAMP(4 * (2 - l) + 2);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           u32x4 gf[4], af[4];
@@ -239,6 +256,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         db[l][0] += s0;
         db[l][1] += s1;
+        EF_STAMP(4 * (2 - l) + 3);
       }
     }
     // partial results of this workgroup: dW[l][n][k] (lane holds rows n = 64 gi + 16 x + 4 g + j, column k = 64 gj + 16 y + r)
@@ -289,6 +307,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = int(blockIdx.x) + it * int(gridDim.x);
+    EF_STAMP(0);
     // ---- requests of this tile's gradient inputs (consumed after the two forward Linears) and of the next tile's endpoints
     f32x4 dy[NB];
     u32x2 yb[NB];
@@ -315,11 +334,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     u32x4 a0p[4], a1p[4], a2p[4];
     relu_pack(a0p, act);
+    EF_STAMP(1);
     f32x4 acc[NB];
     stage_fwd(acc, a0p, W1, b1, fb, g);
     relu_pack(a1p, acc);
+    EF_STAMP(2);
     stage_fwd(acc, a1p, W2, b2, fb, g);
     relu_pack(a2p, acc);
+    EF_STAMP(3);
     // ---- LayerNorm backward (no affine): g_3 = rstd * (dy - mean(dy) - y * mean(dy * y))   (chain.hip: k_chain_bwd)
     f32x4 gr[NB];
     {
@@ -345,29 +367,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fib = *reinterpret_cast<const float4*>(a.fiber + size_t(nxt.row) * 4);
     u32x4 gb[4];
     pack(gb, gr);
+    EF_STAMP(4);
     // ---- Linear 3: (G_3, A_2) -> gradient waves; g_2 = (W_3^T g_3) . [a_2 > 0]
     lds_barrier();
+    EF_STAMP(5);
     stage_rows(GST, sb, gb);
     stage_rows(AST, sb, a2p);
     lds_barrier();
+    EF_STAMP(6);
     stage_bwd(acc, gb, W3, tb);
     mask_by(gr, acc, a2p);
     pack(gb, gr);
+    EF_STAMP(7);
     // ---- Linear 2
     lds_barrier();
+    EF_STAMP(8);
     stage_rows(GST, sb, gb);
     stage_rows(AST, sb, a1p);
     lds_barrier();
+    EF_STAMP(9);
     stage_bwd(acc, gb, W2, tb);
     mask_by(gr, acc, a1p);
     pack(gb, gr);
+    EF_STAMP(10);
     // ---- Linear 1
     lds_barrier();
+    EF_STAMP(11);
     stage_rows(GST, sb, gb);
     stage_rows(AST, sb, a0p);
     lds_barrier();
+    EF_STAMP(12);
     stage_bwd(acc, gb, W1, tb);
     mask_by(gr, acc, a0p);
+    EF_STAMP(13);
     // ---- g_0 -> HBM as bf16 (input of the scatter / fiber-gradient kernel) + its magnitude bound
     {
       float m = 0.f;
@@ -383,6 +415,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int t = 0; t < NB; ++t) op[4 * t] = u32x2{pk_bf16(gr[t][0], gr[t][1]), pk_bf16(gr[t][2], gr[t][3])};
       }
     }
+    EF_STAMP(14);
     cur = nxt;
   }
   if (a.gmax) {   // bound slot of gE[0] (chain.h: kBoundWidth): this wave's entry
@@ -433,16 +466,23 @@ __global__ __launch_bounds__(256) void k_ef_reduce(const float* part, int nwg, f
     }
     return;
   }
-  // bias gradients: 3 x 128 outputs, each the sum of nwg x 4 partials (workgroup-major, then gradient wave)
-  const int o = (int(blockIdx.x) - NBLK) * 256 + tid;
-  if (o >= 3 * D) return;
+  // bias gradients: 3 x 128 outputs, each the sum of nwg x 4 partials (per split: workgroup order; then split order)
+  __shared__ float redb[8][32];
+  const int e = tid & 31, sp = tid >> 5;
+  const int o = (int(blockIdx.x) - NBLK) * 32 + e;     // 12 blocks x 32 outputs
   const int l = o / D, n = o - l * D;
-  float s = 0.f;
-  for (int w = 0; w < nwg; ++w) {
+  float sum = 0.f;
+  for (int w = sp; w < nwg; w += 8) {
     const float* p = part + size_t(w) * (DW_FLOATS + DB_FLOATS) + DW_FLOATS + l * 4 * D + n;
-    s += (p[0] + p[D]) + (p[2 * D] + p[3 * D]);
+    sum += (p[0] + p[D]) + (p[2 * D] + p[3 * D]);
   }
-  (l == 0 ? db0 : (l == 1 ? db1 : db2))[n] = s;
+  redb[sp][e] = sum;
+  __syncthreads();
+  if (sp == 0) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) sum += redb[k][e];
+    (l == 0 ? db0 : (l == 1 ? db1 : db2))[n] = sum;
+  }
 }
 
 int device_cus_ef() {
@@ -480,7 +520,7 @@ int launch_edge_fused_bwd(EdgeFusedBwdArgs a, int* nwg_out, hipStream_t s) {
 
 // the fixed-order sum of the workgroups' partials into the three weight / bias gradients (stream-ordered after the kernel above)
 int launch_edge_fused_reduce(const float* part, int nwg, float* const dW[3], float* const db[3], hipStream_t s) {
-  hipLaunchKernelGGL(k_ef_reduce, dim3(DW_FLOATS / 4 / 32 + 2), dim3(256), 0, s, part, nwg, dW[0], dW[1], dW[2], db[0], db[1], db[2]);
+  hipLaunchKernelGGL(k_ef_reduce, dim3(DW_FLOATS / 4 / 32 + 3 * D / 32), dim3(256), 0, s, part, nwg, dW[0], dW[1], dW[2], db[0], db[1], db[2]);
   BSMS_LAUNCH_CHECK();
   return BSMS_OK;
 }

@@ -395,6 +395,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.dy = wk.daggr; a.y = sv.e_y; a.rstd = sv.e_rstd; a.g0 = wk.gE[0];
     a.gmax = sv.bound + size_t(16 + H) * kBoundWidth;
     a.part = wk.ef_part;
+    a.timing = g_timing;
     if ((rc = launch_edge_fused_bwd(a, &ef_nwg, s))) return rc;
   } else {
     ChainBwdArgs a{};
