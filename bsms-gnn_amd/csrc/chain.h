@@ -246,6 +246,26 @@ size_t edge_fused_part_floats();
 int launch_edge_fused_bwd(EdgeFusedBwdArgs a, int* nwg_out, hipStream_t s);
 int launch_edge_fused_reduce(const float* part, int nwg, float* const dW[3], float* const db[3], hipStream_t s);
 
+// efwd.hip: the edge MLP forward of the bf16 precisions with the three D x D weights resident in LDS (D = 128, hidden = 3):
+// 16 independent waves per workgroup, no weight ring, no barriers; bit-identical to k_chain_fwd<8, IN_EDGE, OUT_LN, BF>
+struct EdgeFwdResArgs {
+  int64_t R;                  // B * E edge rows (plan order)
+  int32_t E, N;
+  const int32_t *src, *dst;   // plan-order endpoints
+  const float *Ps, *Pd;       // node projections [B*N, D]
+  const float* pos;           // [B, N, p] (batch stride pos_bstride; 0 = one point set for every sample)
+  int64_t pos_bstride;
+  int p;
+  const float* wft;           // fiber weights^T [p+1][D]
+  const float4* wp[3];        // the one-plane bf16 packs of edge Linears 1..3 (PackDesc::bf16; bias in the header of chunk 0)
+  void* y;                    // [R, D] bf16 messages
+  float* rstd;                // [R] (nullable: inference)
+  float* fiber_out;           // [R, 4] (nullable: inference)
+  int ntiles;                 // filled by the launcher
+};
+bool edge_fwd_res_supported(int64_t D, int H, int64_t p, int precision);
+int launch_edge_fwd_res(EdgeFwdResArgs a, hipStream_t s);
+
 // from rowsum.hip
 int rowsum_plan_order(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);
 int rowsum_by_source(const bsms_plan* p, const float* x, int64_t B, int64_t D, float* out, hipStream_t s);

@@ -137,6 +137,20 @@ __device__ __forceinline__ void mask_by(f32x4 (&g)[NB], const f32x4 (&acc)[NB], 
       g[t][j] = pos ? acc[t][j] : 0.f;
     }
 }
+// mask_by + pack in one: the packed bf16 gradient pair AND-ed with an all-ones / zero half-word mask made from the packed
+// activation pair (two packed operations per PAIR instead of compare + select per element); same bits as pack(mask_by(.))
+__device__ __forceinline__ void mask_pack(u32x4 (&gb)[4], const f32x4 (&acc)[NB], const u32x4 (&ap)[4]) {
+  const unsigned ones = 0x00010001u;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      unsigned m;   // (inline asm: left to itself hipcc reasons about the bf16 conversion that made `ap` and emits ten compares per pair)
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(ap[c][v]), "s"(ones));   // 1 where a > 0 (a >= +0: bits != 0)
+      asm("v_pk_sub_u16 %0, 0, %1" : "=v"(m) : "v"(m));                      // 0xffff / 0
+      gb[c][v] = pk_bf16(acc[2 * c + (v >> 1)][2 * (v & 1)], acc[2 * c + (v >> 1)][2 * (v & 1) + 1]) & m;
+    }
+}
 // acc = bias + W x   (forward direction; each accumulator takes its K chunks in the order 0..3 like chain.hip: mfma_stage_bf)
 __device__ __forceinline__ void stage_fwd(f32x4 (&acc)[NB], const u32x4 (&bb)[4], const char* W, const float* bias, unsigned fb, int g) {
 #pragma unroll
@@ -171,13 +185,18 @@ __device__ __forceinline__ void load_rows(f32x4 (&v)[NBX], const float* row, int
   for (int t = 0; t < NBX; ++t) v[t] = *reinterpret_cast<const f32x4*>(row + 16 * t + 4 * g);
 }
 
-// experiments (profiles/ef_timeline.py): phase stamps of chain wave 0 / gradient wave 4, 16 + 16 slots per tile
+// experiments (profiles/ef_timeline.py): phase stamps of chain wave 0 (slots 0-23) / gradient wave 4 (24-39), 40 slots per tile
 #ifdef BSMS_EXPERIMENTS
+#ifdef EFV_NOGSTAMP   // variant: no stamps in the gradient wave (do its stamp stores, queued behind the chain waves' gathers, stall it?)
+#define EF_STAMP_WAVES (wave == 0)
+#else
+#define EF_STAMP_WAVES (wave == 0 || wave == 4)
+#endif
 #define EF_STAMP(slot)                                                                                          \
   do {                                                                                                           \
-    if (a.timing && lane == 0 && (wave == 0 || wave == 4)) {                                                     \
+    if (a.timing && lane == 0 && EF_STAMP_WAVES) {                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                         \
-      a.timing[size_t(int(blockIdx.x) + it * int(gridDim.x)) * 32 + (wave == 4 ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memtime(); \
+      a.timing[size_t(int(blockIdx.x) + it * int(gridDim.x)) * 40 + (wave == 4 ? 24 : 0) + (slot)] = __builtin_amdgcn_s_memtime(); \
       __builtin_amdgcn_sched_barrier(0);                                                                         \
     }                                                                                                            \
   } while (0)
@@ -287,15 +306,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float gmax = 0.f;
 
   // what a tile needs from the plan: node rows of the two endpoints and the edge row itself
-  struct Where { unsigned row; bool live; unsigned isrc, idst; };
+  struct Where { unsigned row, srow; bool live; unsigned isrc, idst; };
+  const float rcpE = 1.f / float(a.E);
   auto locate = [&](int tile) {
     Where wq;
     const int64_t row64 = int64_t(tile) * ST_ROWS + wave * 16 + r;
     wq.live = row64 < a.R;
-    wq.row = wq.live ? unsigned(row64) : 0u;   // lanes past the end read row 0; nothing of theirs is stored or summed
-    const unsigned b = wq.row / uE, q = wq.row - b * uE;
-    wq.isrc = b * uN + unsigned(a.src[q]);
-    wq.idst = b * uN + unsigned(a.dst[q]);
+    wq.srow = unsigned(row64);                 // where this lane STORES: rows past R are padding of g0 (chain.h: pad_rows), never read
+    wq.row = wq.live ? unsigned(row64) : 0u;   // lanes past the end read row 0; nothing of theirs is summed
+    // row -> (batch, edge) without an integer division: reciprocal estimate, corrected by at most one step (rows < 2^31, launcher)
+    int b = int(float(wq.row) * rcpE);
+    int q = int(wq.row) - b * int(uE);
+    if (q < 0) { q += int(uE); --b; }
+    if (q >= int(uE)) { q -= int(uE); ++b; }
+    wq.isrc = unsigned(b) * uN + unsigned(a.src[q]);
+    wq.idst = unsigned(b) * uN + unsigned(a.dst[q]);
     return wq;
   };
   f32x4 ps[NB], pd[NB];
@@ -304,6 +329,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   load_rows<NB>(ps, a.Ps + size_t(cur.isrc) * D, g);
   load_rows<NB>(pd, a.Pd + size_t(cur.idst) * D, g);
   fib = *reinterpret_cast<const float4*>(a.fiber + size_t(cur.row) * 4);
+  // g_0 of the PREVIOUS tile, packed: its eight stores are issued two at a time between the phases of the next tile.  Issued
+  // right after dgrad 1 they (a) fill the CU's store path in one burst and (b) sit, in the in-order vmcnt queue, between the
+  // endpoint rows requested a tile ahead and their first use, which then waits for the stores to be acknowledged
+  // (profiles/r05_ef_timeline_before.txt: 3.2k + 3.0k of 22k cycles per tile).
+  u32x4 g0p[4] = {};
+  unsigned g0row = 0;
+  auto store_g0 = [&](int t0) {   // feature blocks t0, t0 + 1 of the previous tile's rows
+    u32x2* op = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.g0) + size_t(g0row) * D + 4 * g);
+    op[4 * t0] = u32x2{g0p[t0 >> 1][0], g0p[t0 >> 1][1]};
+    op[4 * t0 + 4] = u32x2{g0p[t0 >> 1][2], g0p[t0 >> 1][3]};
+    __builtin_amdgcn_sched_barrier(0);
+  };
 
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = int(blockIdx.x) + it * int(gridDim.x);
@@ -335,13 +372,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     u32x4 a0p[4], a1p[4], a2p[4];
     relu_pack(a0p, act);
     EF_STAMP(1);
+    if (it > 0) store_g0(0);
     f32x4 acc[NB];
     stage_fwd(acc, a0p, W1, b1, fb, g);
     relu_pack(a1p, acc);
     EF_STAMP(2);
+    if (it > 0) store_g0(2);
     stage_fwd(acc, a1p, W2, b2, fb, g);
     relu_pack(a2p, acc);
     EF_STAMP(3);
+    if (it > 0) store_g0(4);
     // ---- LayerNorm backward (no affine): g_3 = rstd * (dy - mean(dy) - y * mean(dy * y))   (chain.hip: k_chain_bwd)
     f32x4 gr[NB];
     {
@@ -361,46 +401,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) gr[t][j] = keep * (rstd * (dy[t][j] - m1 - act[t][j] * m2));
     }
+    if (it > 0) store_g0(6);
     // ---- the next tile's endpoint rows are requested now: they land under the three gradient stages
+#ifndef EFV_LATEPF
     load_rows<NB>(ps, a.Ps + size_t(nxt.isrc) * D, g);
     load_rows<NB>(pd, a.Pd + size_t(nxt.idst) * D, g);
     fib = *reinterpret_cast<const float4*>(a.fiber + size_t(nxt.row) * 4);
+#endif
     u32x4 gb[4];
     pack(gb, gr);
     EF_STAMP(4);
-    // ---- Linear 3: (G_3, A_2) -> gradient waves; g_2 = (W_3^T g_3) . [a_2 > 0]
-    lds_barrier();
-    EF_STAMP(5);
-    stage_rows(GST, sb, gb);
-    stage_rows(AST, sb, a2p);
-    lds_barrier();
-    EF_STAMP(6);
-    stage_bwd(acc, gb, W3, tb);
-    mask_by(gr, acc, a2p);
-    pack(gb, gr);
-    EF_STAMP(7);
-    // ---- Linear 2
-    lds_barrier();
-    EF_STAMP(8);
-    stage_rows(GST, sb, gb);
-    stage_rows(AST, sb, a1p);
-    lds_barrier();
-    EF_STAMP(9);
-    stage_bwd(acc, gb, W2, tb);
-    mask_by(gr, acc, a1p);
-    pack(gb, gr);
-    EF_STAMP(10);
-    // ---- Linear 1
-    lds_barrier();
-    EF_STAMP(11);
-    stage_rows(GST, sb, gb);
-    stage_rows(AST, sb, a0p);
-    lds_barrier();
-    EF_STAMP(12);
-    stage_bwd(acc, gb, W1, tb);
+    // ---- one gradient stage: acc = W_l^T g_l, and in the middle of it (G_l, A_{l-1}) of this wave's 16 rows go to the gradient
+    // waves.  The hand-over sits INSIDE the stage: barrier X (everybody has finished reading the previous pair) is reached two
+    // K chunks after the previous stage's barrier Y, when the gradient waves are (nearly) done, and the staging stores land under
+    // the third chunk's MFMAs instead of in front of an idle barrier (before: 3 x 1.25k cycles at Y, up to 2.4k at X per tile).
+    auto chunk_bwd = [&](const char* W, int c) {
+#pragma unroll
+      for (int t = 0; t < NB; ++t) acc[t] = mma(frag_col(W, tb, c, t), gb[c], acc[t]);
+    };
+#define EF_DGRAD(W, AP, K)                                                         \
+    do {                                                                           \
+      _Pragma("unroll") for (int t = 0; t < NB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+      chunk_bwd(W, 0);                                                             \
+      chunk_bwd(W, 1);                                                             \
+      EF_STAMP(5 + 4 * (K));                                                       \
+      lds_barrier(); /* X */                                                       \
+      EF_STAMP(6 + 4 * (K));                                                       \
+      stage_rows(GST, sb, gb);                                                     \
+      stage_rows(AST, sb, AP);                                                     \
+      chunk_bwd(W, 2);                                                             \
+      EF_STAMP(7 + 4 * (K));                                                       \
+      lds_barrier(); /* Y */                                                       \
+      EF_STAMP(8 + 4 * (K));                                                       \
+      chunk_bwd(W, 3);                                                             \
+    } while (0)
+    EF_DGRAD(W3, a2p, 0);        // Linear 3: g_2 = (W_3^T g_3) . [a_2 > 0]
+    mask_pack(gb, acc, a2p);
+#ifdef EFV_LATEPF   // variant: the prefetch after the first gradient stage
+    load_rows<NB>(ps, a.Ps + size_t(nxt.isrc) * D, g);
+    load_rows<NB>(pd, a.Pd + size_t(nxt.idst) * D, g);
+    fib = *reinterpret_cast<const float4*>(a.fiber + size_t(nxt.row) * 4);
+#endif
+    EF_DGRAD(W2, a1p, 1);        // Linear 2
+    mask_pack(gb, acc, a1p);
+    EF_DGRAD(W1, a0p, 2);        // Linear 1
     mask_by(gr, acc, a0p);
-    EF_STAMP(13);
-    // ---- g_0 -> HBM as bf16 (input of the scatter / fiber-gradient kernel) + its magnitude bound
+#undef EF_DGRAD
+    EF_STAMP(17);
+    // ---- g_0 (bf16: input of the scatter / fiber-gradient kernel) is kept packed for the deferred stores + its magnitude bound
     {
       float m = 0.f;
 #pragma unroll
@@ -409,14 +457,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         m = fmaxf(fmaxf(m, fabsf(gr[t][2])), fabsf(gr[t][3]));
       }
       gmax = fmaxf(gmax, m);
-      if (cur.live) {
-        u32x2* op = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.g0) + size_t(cur.row) * D + 4 * g);
-#pragma unroll
-        for (int t = 0; t < NB; ++t) op[4 * t] = u32x2{pk_bf16(gr[t][0], gr[t][1]), pk_bf16(gr[t][2], gr[t][3])};
-      }
+      pack(g0p, gr);
+      g0row = cur.srow;
     }
-    EF_STAMP(14);
+    EF_STAMP(18);
     cur = nxt;
+  }
+  if (my_tiles > 0) {   // the last tile's g_0
+    store_g0(0); store_g0(2); store_g0(4); store_g0(6);
   }
   if (a.gmax) {   // bound slot of gE[0] (chain.h: kBoundWidth): this wave's entry
 #pragma unroll

@@ -142,6 +142,12 @@ static const int g_edge_fused = env_fused();
 #else
 constexpr int g_edge_fused = 1;
 #endif
+#ifdef BSMS_EXPERIMENTS
+static int env_fwd_res() { const char* e = getenv("BSMS_EDGE_FWD_RES"); return e ? atoi(e) : 1; }
+static const int g_edge_fwd_res = env_fwd_res();   // A/B against the generic ring kernel (profiles/r05_efwd_ab.sh)
+#else
+constexpr int g_edge_fwd_res = 1;
+#endif
 bool use_edge_fused(int64_t D, int H, int precision) { return g_edge_fused && edge_fused_supported(D, H, 1, precision); }
 
 int check_gmp(const bsms_plan_t* plan, int64_t B, int64_t D, int64_t p, int H, const char* who) {
@@ -272,7 +278,16 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     if ((rc = launch_chain_fwd((int)D, IN_ROWS, OUT_PLAIN2, a, s))) return rc;
   }
   // edge MLP + LayerNorm
-  {
+  // bf16 precisions at D = 128, hidden = 3: the kernel with LDS-resident weights (efwd.hip) -- whenever no edge activation has to
+  // be saved, i.e. inference and the training forward of the fused backward (efuse.hip recomputes them)
+  if (g_edge_fwd_res && edge_fwd_res_supported(D, H, p, precision) && (!training || fused)) {
+    EdgeFwdResArgs a{};
+    a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
+    a.Ps = Ps; a.Pd = Pd; a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p; a.wft = sv.e_wft;
+    for (int l = 1; l <= 3; ++l) a.wp[l - 1] = reinterpret_cast<const float4*>(sv.e_w[l]);
+    a.y = sv.e_y; a.rstd = training ? sv.e_rstd : nullptr; a.fiber_out = training ? sv.e_fiber : nullptr;
+    if ((rc = launch_edge_fwd_res(a, s))) return rc;
+  } else {
     ChainFwdArgs a{};
     a.R = B * E; a.K0 = int(p + 1); a.w0t = sv.e_wft; a.store_in = fused ? nullptr : sv.e_act[0];
     a.src = plan->src; a.dst = plan->dst; a.E = (int32_t)E; a.N = (int32_t)N;

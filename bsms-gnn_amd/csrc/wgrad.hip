@@ -800,10 +800,15 @@ int launch_wgrad(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t
   if (skip) return BSMS_OK;
 #endif
   WgradJob part[kMaxWgradJobs];
+#ifdef BSMS_EXPERIMENTS
+  static const bool force_bf3 = [] { const char* e = getenv("BSMS_WGRAD_BF3"); return e && atoi(e) != 0; }();   // A/B: range-free six-product arithmetic for every fp32 job
+#else
+  constexpr bool force_bf3 = false;
+#endif
   for (int mode = 0; mode < 3; ++mode) {   // 0: fp32 with bounds (fp16 x 2), 1: fp32 without (bf16 x 3), 2: bf16 tensors
     int n = 0;
     for (int j = 0; j < njobs; ++j) {
-      const int m = jobs[j].bf16 ? 2 : ((jobs[j].g_bound && jobs[j].a_bound) ? 0 : 1);
+      const int m = jobs[j].bf16 ? 2 : ((jobs[j].g_bound && jobs[j].a_bound && !force_bf3) ? 0 : 1);
       if (m == mode) part[n++] = jobs[j];
     }
     if (n) {
