@@ -145,7 +145,7 @@ struct ChainBwdArgs {
 };
 
 // prepack table ---------------------------------------------------------------------------------
-enum PackKind { PACK_FRAG = 0, PACK_FRAG_T = 1, PACK_TRANSPOSE = 2 };
+enum PackKind { PACK_FRAG = 0, PACK_FRAG_T = 1, PACK_TRANSPOSE = 2, PACK_ROWS_BF16 = 3 };
 struct PackDesc {
   const float* W;  // row-major, leading dimension ld
   const float* bias;  // FRAG kinds: [N] copied into the header of the last chunk (bf16: of chunk 0); nullable -> zeros
@@ -154,6 +154,8 @@ struct PackDesc {
   int N, K;  // logical matrix M[n][k], n < N (outputs), k < K (reduction)
   int kind;  // FRAG: M[n][k] = W[row0+n][col0+k]; FRAG_T: M[n][k] = W[row0+k][col0+n];   (N == K, multiple of 32)
              // TRANSPOSE: dst[k*N+n] = W[row0+n][col0+k] (plain, for the small VALU layers)
+             // ROWS_BF16 (N = K = 128): the LDS image of efuse.hip -- row n at byte 288 n, its 8-byte piece `q` (bf16 of
+             //   M[n][4 q .. 4 q + 3], M as FRAG) at piece slot q ^ ((n >> 2) & 3); 36 KB, copied into LDS by LDS-DMA
   int bf16;  // FRAG kinds: ONE plane = the weight rounded to bf16 (bf16 precision)
   int mate;  // FRAG kinds, fp32 path: 1 + index of a pack of the same table that must share this pack's scale 2^k_w (the two
              // halves of a Linear over concatenated inputs accumulate into one set of registers); 0 = none
@@ -229,8 +231,8 @@ struct EdgeFusedBwdArgs {
   const float* fiber;         // [R, 4]: the fiber rows the forward kept
   const float* wft;           // fiber weights^T [p+1][D]
   int p;
-  const float* W[3];          // fp32 weights of edge Linears 1..3, [D][D] row-major (rounded to bf16 as the forward's packs are)
-  const float* b[3];          // their biases
+  const float4* wr[3];        // PACK_ROWS_BF16 images of edge Linears 1..3 (the rounding of the forward's packs)
+  const float* b[3];          // their biases (fp32 parameters)
   const float* dy;            // [B*N, D] gradient of the aggregate (gathered by target)
   const void* y;              // [R, D] bf16 messages
   const float* rstd;          // [R]

@@ -82,6 +82,19 @@ __device__ __forceinline__ RowScale scale_of(float amax, int emin = 12) {
 __device__ __forceinline__ float pack_elem(const PackDesc& d, int n, int k) {
   return (d.kind == PACK_FRAG_T) ? d.W[int64_t(d.row0 + k) * d.ld + d.col0 + n] : d.W[int64_t(d.row0 + n) * d.ld + d.col0 + k];
 }
+// PACK_ROWS_BF16 (chain.h): dword o of the 36 KB image = row n = o / 72, dword w = o % 72 of the row (64 data + 8 padding)
+__device__ __forceinline__ void pack_rows_bf16(const PackDesc& d, int first, int stride) {
+  unsigned* dst = reinterpret_cast<unsigned*>(d.dst);
+  for (int o = first; o < d.N * 72; o += stride) {
+    const int n = o / 72, w = o - n * 72, slot = w >> 1;
+    unsigned v = 0u;
+    if (slot < 32) {
+      const int k = 4 * (slot ^ ((n >> 2) & 3)) + 2 * (w & 1);
+      v = pk_bf16(pack_elem(d, n, k), pack_elem(d, n, k + 1));
+    }
+    dst[o] = v;
+  }
+}
 // pass 1 (one 1024-thread block per pack): 2^-k_w from the largest |M| of the matrix and of its mate -> header float
 // kScaleSlot of chunk 0, where pass 2 and the chain kernels read it
 __global__ __launch_bounds__(1024) void k_pack_scale(PackTable tab) {
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(1024) void k_pack_scale(PackTable tab) {
     for (int o = blockIdx.x * 1024 + threadIdx.x; o < kBoundSlots * kBoundWidth / 4; o += gridDim.x * 1024)
       reinterpret_cast<float4*>(tab.zero)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
   const PackDesc d = tab.d[blockIdx.x];
-  if (d.kind == PACK_TRANSPOSE || d.bf16) return;
+  if (d.kind == PACK_TRANSPOSE || d.kind == PACK_ROWS_BF16 || d.bf16) return;
   __shared__ float red[16];
   float m = 0.f;
   auto scan = [&](const PackDesc& e) {   // coalesced along the rows of W whatever the logical orientation
@@ -114,6 +127,7 @@ __global__ __launch_bounds__(1024) void k_pack_scale(PackTable tab) {
 
 __global__ __launch_bounds__(256) void k_prepack(PackTable tab) {
   const PackDesc d = tab.d[blockIdx.y];
+  if (d.kind == PACK_ROWS_BF16) { pack_rows_bf16(d, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256); return; }
   if (d.kind == PACK_TRANSPOSE) {
     const int total = d.N * d.K;
     for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
@@ -163,6 +177,7 @@ __global__ __launch_bounds__(1024) void k_prepack_fused(PackTable tab) {
     for (int o = wg * 1024 + threadIdx.x; o < kBoundSlots * kBoundWidth / 4; o += nwg * 1024)
       reinterpret_cast<float4*>(tab.zero)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
   const PackDesc d = tab.d[blockIdx.y];
+  if (d.kind == PACK_ROWS_BF16) { pack_rows_bf16(d, blockIdx.x * 1024 + threadIdx.x, gridDim.x * 1024); return; }
   if (d.kind == PACK_TRANSPOSE) {
     const int total = d.N * d.K;
     for (int o = blockIdx.x * 1024 + threadIdx.x; o < total; o += gridDim.x * 1024) {

@@ -20,7 +20,7 @@
 //              ds_read_b64_tr_b16 from the row-major staging tiles, as wgrad.hip does from its planes.  They also sum
 //              the bias gradients (column sums of G_l) from the staged rows.
 //   One chain wave and one gradient wave share a SIMD: the VALU / LDS phases of the one run under the MFMAs of the other.
-// Weights: W_1..W_3 as bf16 (rounded once, like the forward's packs) stay RESIDENT in LDS for the whole launch, row-major
+// Weights: W_1..W_3 as bf16 (rounded once per call by the prepack, like the forward's packs) stay RESIDENT in LDS for the whole launch, row-major
 // [n][k] with a 288-byte pitch and an 8-byte-piece XOR swizzle (piece ^= (row >> 2) & 3).  ONE copy serves both
 // directions: the forward A-fragments are two ds_read_b64 per lane, the transposed (dgrad) fragments two
 // ds_read_b64_tr_b16 -- the K-slot -> feature map of chain.h is exactly what the transposing read delivers.  No loader
@@ -52,6 +52,7 @@ constexpr int OFF_G = 3 * W_BYTES, OFF_A = OFF_G + ST_BYTES, OFF_SIDE = OFF_A + 
 constexpr int SIDE_WFT = 0, SIDE_B1 = 4 * D * 4, SIDE_B2 = SIDE_B1 + D * 4;
 constexpr int LDS_BYTES = OFF_SIDE + SIDE_B2 + D * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+static_assert(W_BYTES % 1024 == 0, "whole LDS-DMA pieces");
 constexpr int DW_FLOATS = 3 * D * D, DB_FLOATS = 3 * 4 * D;   // partials of one workgroup
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
@@ -62,6 +63,12 @@ __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u 
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_dst, +1 KB) in lane order (chain.hip: glds16)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -207,14 +214,15 @@ __device__ __forceinline__ void load_rows(f32x4 (&v)[NBX], const float* row, int
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_fused_bwd(EdgeFusedBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- prologue: the three weight matrices -> bf16, swizzled row-major; fiber weights and the two forward biases
-  for (int l = 0; l < 3; ++l) {
-    const float* W = a.W[l];
-#pragma unroll 4
-    for (int idx = tid; idx < D * 32; idx += 512) {
-      const int n = idx >> 5, pc = idx & 31;
-      const float4 v = *reinterpret_cast<const float4*>(W + n * D + 4 * pc);
-      *reinterpret_cast<u32x2*>(lds + l * W_BYTES + piece_off(n, pc)) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
+  // ---- prologue: the three PACK_ROWS_BF16 images (bf16, swizzled row-major: written once per call by the block's prepack) go
+  // straight from L2 into LDS with LDS-DMA, 108 pieces of 1 KB over the eight waves -- one round trip instead of the six
+  // dependent batches of fp32 loads + conversion the first version paid per launch (~4 us of a 29 us coarse-level launch)
+  {
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    for (int piece = uwave; piece < 3 * (W_BYTES / 1024); piece += 8) {
+      const int l = piece / (W_BYTES / 1024), k = piece - l * (W_BYTES / 1024);
+      const char* src = reinterpret_cast<const char*>(a.wr[l]) + k * 1024 + lane * 16;
+      glds16(src, __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + unsigned(piece) * 1024u));
     }
   }
   {
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid < D) side[SIDE_B1 / 4 + tid] = a.b[0][tid];
     else if (tid < 2 * D) side[SIDE_B2 / 4 + tid - D] = a.b[1][tid - D];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int my_tiles = (a.ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
   const char* const W1 = lds, * const W2 = lds + W_BYTES, * const W3 = lds + 2 * W_BYTES;
@@ -450,13 +459,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     EF_STAMP(17);
     // ---- g_0 (bf16: input of the scatter / fiber-gradient kernel) is kept packed for the deferred stores + its magnitude bound
     {
-      float m = 0.f;
+      if (a.gmax) {   // uniform (null when nobody consumes the bound: the projections' weight gradients run range-free, gmp.hip)
+        float m = 0.f;
 #pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        m = fmaxf(fmaxf(m, fabsf(gr[t][0])), fabsf(gr[t][1]));
-        m = fmaxf(fmaxf(m, fabsf(gr[t][2])), fabsf(gr[t][3]));
+        for (int t = 0; t < NB; ++t) {
+          m = fmaxf(fmaxf(m, fabsf(gr[t][0])), fabsf(gr[t][1]));
+          m = fmaxf(fmaxf(m, fabsf(gr[t][2])), fabsf(gr[t][3]));
+        }
+        gmax = fmaxf(gmax, m);
       }
-      gmax = fmaxf(gmax, m);
       pack(g0p, gr);
       g0row = cur.srow;
     }

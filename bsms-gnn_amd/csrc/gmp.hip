@@ -63,6 +63,7 @@ struct GmpSaved {
   float *n_act[kMaxStages], *n_yln, *n_rstd;
   // packs (fragment order)
   float *e_wi, *e_wj, *e_wft, *e_w[kMaxStages], *e_wt[kMaxStages], *e_wit, *e_wjt;
+  float* e_wr[kMaxStages];   // fused edge backward: PACK_ROWS_BF16 images of the D x D edge Linears (efuse.hip)
   float *n_w0x, *n_w0a, *n_w[kMaxStages], *n_wt[kMaxStages], *n_w0xt, *n_w0at;
   // magnitude bounds (training; chain.h: kBoundSlots floats, zeroed by the block's prepack): [0..7] tensor entering edge
   // forward stage l (e_act[l]); [8..15] node forward stage l ([8]: x and aggr jointly, [8 + l]: n_act[l - 1]);
@@ -100,7 +101,7 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
   Carver& k = packs_base ? cp : c;
   s.e_wi = k.take(dd); s.e_wj = k.take(dd); s.e_wft = k.take(size_t(8) * D);
   if (training) { s.e_wit = k.take(dd); s.e_wjt = k.take(dd); }
-  for (int l = 1; l <= H; ++l) { s.e_w[l] = k.take(dd); if (training) s.e_wt[l] = k.take(dd); }
+  for (int l = 1; l <= H; ++l) { s.e_w[l] = k.take(dd); if (training && !fused) s.e_wt[l] = k.take(dd); if (training && fused) s.e_wr[l] = k.take(size_t(D) * 72); }
   s.n_w0x = k.take(dd); s.n_w0a = k.take(dd);
   if (training) { s.n_w0xt = k.take(dd); s.n_w0at = k.take(dd); }
   for (int l = 1; l <= H; ++l) { s.n_w[l] = k.take(dd); if (training) s.n_wt[l] = k.take(dd); }
@@ -141,6 +142,16 @@ static int env_fused() { const char* e = getenv("BSMS_EDGE_FUSED"); return e ? a
 static const int g_edge_fused = env_fused();
 #else
 constexpr int g_edge_fused = 1;
+#endif
+// Weight gradients of the NODE-level Linears (node MLP, the two projections, the encoder / decoder MLPs): the range-free
+// three-way bf16 split (wgrad.hip: BF3, six products) instead of fp16 x 2 pieces with one scale per tensor -- their operands
+// include caller-supplied tensors whose columns may differ by any factor, and they
+// are ~15 % of the weight-gradient work.  Experiment builds can switch back for A/B runs (BSMS_NODE_BF3=0).
+#ifdef BSMS_EXPERIMENTS
+static int env_node_bf3() { const char* e = getenv("BSMS_NODE_BF3"); return e ? atoi(e) : 1; }
+static const int g_node_bf3 = env_node_bf3();
+#else
+constexpr int g_node_bf3 = 1;
 #endif
 #ifdef BSMS_EXPERIMENTS
 static int env_fwd_res() { const char* e = getenv("BSMS_EDGE_FWD_RES"); return e ? atoi(e) : 1; }
@@ -204,7 +215,8 @@ int prepack_block(const GmpSaved& sv, int64_t D, int64_t p, int H, bool training
   for (int l = 1; l <= H; ++l) {   // the D x D Linears of the edge MLP: bf16 operands in the bf16 precision
     add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG, sv.e_w[l], pe[2 * l + 1]);
     t.d[t.n - 1].bf16 = bf;
-    if (training) { add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]); t.d[t.n - 1].bf16 = bf; }
+    if (training && sv.e_wt[l]) { add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_FRAG_T, sv.e_wt[l]); t.d[t.n - 1].bf16 = bf; }
+    if (training && sv.e_wr[l]) add_pack(t, pe[2 * l], (int)D, 0, 0, (int)D, (int)D, PACK_ROWS_BF16, sv.e_wr[l]);   // fused edge backward (efuse.hip)
   }
   // first node Linear over [x, aggr]: two packs, one scale; the bias rides in the second one (where the stage finishes).
   // BSMS_BF16_NODES: one-plane packs of the rounded weights; a bf16 stage STARTS from its pack's bias (chunk 0 header), so
@@ -325,8 +337,10 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     }
     a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x; a.resid2 = resid2;
     a.bf16 = bfn;
-    if (training && !bfn) for (int st = 0; st <= H; ++st) a.amax[st] = sv.bound + size_t(8 + st) * kBoundWidth;
-    else if (training) a.amax[0] = sv.bound + size_t(8) * kBoundWidth;   // BSMS_BF16_NODES: only [x, aggr] feed an fp32 weight-gradient job
+    if (!g_node_bf3) {   // (A/B only: bounds for the fp16 x 2 weight-gradient arithmetic)
+      if (training && !bfn) for (int st = 0; st <= H; ++st) a.amax[st] = sv.bound + size_t(8 + st) * kBoundWidth;
+      else if (training) a.amax[0] = sv.bound + size_t(8) * kBoundWidth;   // BSMS_BF16_NODES: only [x, aggr] feed an fp32 weight-gradient job
+    }
     a.store_mode = 1;
     a.timing = (g_debug_flags & 512) ? g_timing : nullptr;
     if ((rc = launch_chain_fwd((int)D, IN_ROWS2, OUT_LN, a, s))) return rc;
@@ -396,8 +410,10 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.wh1 = reinterpret_cast<const float4*>(sv.n_w0at);
     a.dx = grad_x; a.dx2 = wk.daggr; a.dres = grad_out;
     a.bf16 = bfn;
-    if (!bfn) for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(24 + k) * kBoundWidth;
-    else a.gmax[H] = sv.bound + size_t(24 + H) * kBoundWidth;   // BSMS_BF16_NODES: only gN[0] (fp32) feeds an fp32 weight-gradient job
+    if (!g_node_bf3) {
+      if (!bfn) for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(24 + k) * kBoundWidth;
+      else a.gmax[H] = sv.bound + size_t(24 + H) * kBoundWidth;   // BSMS_BF16_NODES: only gN[0] (fp32) feeds an fp32 weight-gradient job
+    }
     if ((rc = launch_chain_bwd((int)D, G_ROWS_LN, F_HEADS2, a, s))) return rc;
   }
   // edge MLP backward (gradient of the aggregation = gather by target)
@@ -406,9 +422,9 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
     a.Ps = sv.e_Ps; a.Pd = sv.e_Pd; a.fiber = sv.e_fiber; a.wft = sv.e_wft; a.p = (int)p;
     const float* const* pe = params + 2 * nl;
-    for (int l = 1; l <= 3; ++l) { a.W[l - 1] = pe[2 * l]; a.b[l - 1] = pe[2 * l + 1]; }
+    for (int l = 1; l <= 3; ++l) { a.wr[l - 1] = reinterpret_cast<const float4*>(sv.e_wr[l]); a.b[l - 1] = pe[2 * l + 1]; }
     a.dy = wk.daggr; a.y = sv.e_y; a.rstd = sv.e_rstd; a.g0 = wk.gE[0];
-    a.gmax = sv.bound + size_t(16 + H) * kBoundWidth;
+    a.gmax = g_node_bf3 ? nullptr : sv.bound + size_t(16 + H) * kBoundWidth;   // only the projections' weight gradients used it
     a.part = wk.ef_part;
     a.timing = g_timing;
     if ((rc = launch_edge_fused_bwd(a, &ef_nwg, s))) return rc;
@@ -424,8 +440,8 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       a.mask[k] = sv.e_act[H - k - 1];
       a.gstore[k + 1] = wk.gE[H - k - 1];
     }
-    if (!bf) for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(16 + k) * kBoundWidth;
-    else a.gmax[H] = sv.bound + size_t(16 + H) * kBoundWidth;   // bf16 precision: only gE[0] (fp32 scatter sums dPs / dPd feed fp32 weight-gradient jobs)
+    if (!bf) for (int k = 0; k <= (g_node_bf3 ? H - 1 : H); ++k) a.gmax[k] = sv.bound + size_t(16 + k) * kBoundWidth;   // gE[0] feeds only the projections' jobs
+    else if (!g_node_bf3) a.gmax[H] = sv.bound + size_t(16 + H) * kBoundWidth;   // bf16 precision: only gE[0] (fp32 scatter sums dPs / dPd feed fp32 weight-gradient jobs)
     if ((rc = launch_chain_bwd((int)D, G_EDGE_LN, F_NONE, a, s))) return rc;
   }
   // From here two independent strands run CONCURRENTLY (fork/join on an internal side stream):
@@ -463,12 +479,13 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0, bd(16 + (H - l)), bd(l - 1));
       jobs[nj - 1].bf16 = bf;
     }
+    auto nbd = [&](int slot) -> const float* { return g_node_bf3 ? nullptr : bd(slot); };   // node level: no bounds = the range-free arithmetic
     for (int l = 1; l <= H; ++l) {   // node Linears 1..H: bf16 tensors in BSMS_BF16_NODES
-      add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0, bd(24 + (H - l)), bd(8 + l));
+      add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0, nbd(24 + (H - l)), nbd(8 + l));
       jobs[nj - 1].bf16 = bfn;
     }
-    add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0, bd(24 + H), bd(8));
-    add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D, bd(24 + H), bd(8));
+    add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0, nbd(24 + H), nbd(8));
+    add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D, nbd(24 + H), nbd(8));
     if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, ws))) return rc;
   }
   // a second side stream takes the remaining weight gradients of the first edge Linear (fiber columns + bias now,
@@ -514,7 +531,8 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     auto set = [&](WgradJob& j, const float* G, int col0) {
       j.G = G; j.A = x; j.dW = ge[0]; j.db = nullptr; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldE0; j.col0 = col0; j.bf16 = 0;
       // dPs / dPd are sums of at most max-degree rows of gE[0]; x is covered by the joint bound of the node chain's input
-      j.g_bound = sv.bound + size_t(16 + H) * kBoundWidth; j.a_bound = sv.bound + size_t(8) * kBoundWidth; j.a_mul = 1.f;
+      j.g_bound = g_node_bf3 ? nullptr : sv.bound + size_t(16 + H) * kBoundWidth;
+      j.a_bound = g_node_bf3 ? nullptr : sv.bound + size_t(8) * kBoundWidth; j.a_mul = 1.f;
     };
     set(jobs[0], wk.dPs, int(p + 1));
     set(jobs[1], wk.dPd, int(p + 1 + D));
@@ -649,7 +667,7 @@ extern "C" int bsms_mlp_fwd_ex(const float* x, int64_t R, int64_t in_dim, int64_
   }
   a.nstage = st;
   a.y = y;
-  if (training) for (int k = 0; k < st; ++k) a.amax[k] = sv.bound + size_t(k) * kBoundWidth;
+  if (training && !g_node_bf3) for (int k = 0; k < st; ++k) a.amax[k] = sv.bound + size_t(k) * kBoundWidth;
   if (kind == MLP_ROWS_SMALL) {
     a.wout = params[2 * H]; a.bout = params[2 * H + 1]; a.C = (int)out_dim;
     return launch_chain_fwd((int)D, IN_ROWS, OUT_SMALL, a, s);
@@ -699,7 +717,7 @@ extern "C" int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, i
     a.gstore[k + 1] = wk.g[l - 1];
   }
   a.nstage = k;
-  for (int q = 0; q <= k; ++q) a.gmax[q] = sv.bound + size_t(16 + q) * kBoundWidth;
+  if (!g_node_bf3) for (int q = 0; q <= k; ++q) a.gmax[q] = sv.bound + size_t(16 + q) * kBoundWidth;
   if (kind == MLP_SMALL_LN) {
     rc = launch_chain_bwd((int)D, G_ROWS_LN, F_NONE, a, s);
   } else {
@@ -723,8 +741,8 @@ extern "C" int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, i
     j.G = wk.g[l]; j.A = (l == 0) ? x : sv.act[l - 1];
     j.dW = grads[2 * l]; j.db = grads[2 * l + 1];
     j.R = R; j.ldg = j.lda = j.ldw = (int)D; j.col0 = 0;
-    j.g_bound = sv.bound + size_t(16 + (top - l)) * kBoundWidth;                          // g[l] = gstore[top - l]
-    j.a_bound = sv.bound + size_t(l - (kind == MLP_SMALL_LN ? 1 : 0)) * kBoundWidth;    // the tensor entering the forward stage of Linear l
+    j.g_bound = g_node_bf3 ? nullptr : sv.bound + size_t(16 + (top - l)) * kBoundWidth;                          // g[l] = gstore[top - l]
+    j.a_bound = g_node_bf3 ? nullptr : sv.bound + size_t(l - (kind == MLP_SMALL_LN ? 1 : 0)) * kBoundWidth;    // the tensor entering the forward stage of Linear l
     j.g_mul = j.a_mul = 1.f;
   }
   if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, s))) return rc;

@@ -85,10 +85,12 @@ __device__ __forceinline__ void split_quad_h2(const f32x4& v, float s, u32x2& h,
   h = u32x2{h0, h1};
   l = u32x2{l0, l1};
 }
-// biased exponent E of a bound (clamped so that 2^(139 - E) is a normal float); bound * 2^(139 - E) lies in [2^12, 2^13)
+// biased exponent E of a bound (clamped so that 2^(141 - E) is a normal float); bound * 2^(141 - E) lies in [2^14, 2^15):
+// the largest piece stays below fp16's 65504, and two octaves more of the tensor's range keep a normal low piece than with the
+// chain kernels' [2^12, 2^13) (there the headroom covers the row sums of the LayerNorm; here nothing is added before the MFMA)
 __device__ __forceinline__ int bound_exp(float b) {
   int E = int(__float_as_uint(b) >> 23) & 0xff;
-  return E < 12 ? 12 : E;
+  return E < 14 ? 14 : E;
 }
 
 // MFMA operand of one 16-column block from a row-major plane: lane (c = lane & 15, q = lane >> 4) receives column
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
     for (int w = 0; w < WG_THREADS / 64; ++w) { gm = max(gm, bred[0][w]); am = max(am, bred[1][w]); }
     Eg = bound_exp(__uint_as_float(gm) * job.g_mul);
     Ea = bound_exp(__uint_as_float(am) * job.a_mul);
-    sG = __uint_as_float(unsigned(266 - Eg) << 23);
-    sA = __uint_as_float(unsigned(266 - Ea) << 23);
+    sG = __uint_as_float(unsigned(268 - Eg) << 23);
+    sA = __uint_as_float(unsigned(268 - Ea) << 23);
   }
 
   // staging: 1024 threads move one 32-row chunk of G and of A, one float4 of each per thread (row = tid / 32,
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r)   // H2: un-scale by the exact power of two 2^-(k_G + k_A) (ldexp: exact over the whole range)
-        part[(32 * wr + 16 * a + 4 * q + r) * TB + 32 * wc + 16 * b + cc] = H2 ? ldexpf(acc[a][b][r], Eg + Ea - 278) : acc[a][b][r];
+        part[(32 * wr + 16 * a + 4 * q + r) * TB + 32 * wc + 16 * b + cc] = H2 ? ldexpf(acc[a][b][r], Eg + Ea - 282) : acc[a][b][r];
   if (want_db) {  // combine the 32 row-threads of each column quad in fixed order through LDS
     f32x4* red = reinterpret_cast<f32x4*>(planes);
     red[tid] = csum;

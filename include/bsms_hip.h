@@ -22,13 +22,18 @@
  *     partial products of two-way fp16 splits (11 + 11 significand bits) of power-of-two-scaled fp32 operands.
  *     Forward and input-gradient products scale per activation ROW and per weight MATRIX: the result is at least as
  *     accurate as an fp32 fused-multiply-add chain and as v_mfma_f32_16x16x4_f32 over the whole fp32 range
- *     (chain.h; profiles/census/f16split.hip; tests/test_hip_parity.py).  The WEIGHT gradients reduce over rows, so
- *     they scale per operand TENSOR (from a magnitude bound the chain kernels record): an element within 2^-16 of its
- *     tensor's largest magnitude keeps all 22 bits; below that the low piece is an fp16 subnormal and one bit is lost
- *     per octave (a feature column at 1e-5 of the maximum: ~6e-6 relative error of that column's gradient against
- *     2e-6 for fp32 arithmetic; at 1e-7: ~3e-4).  Activations behind LayerNorm / ReLU and their gradients span far
- *     less than 2^16 per tensor in this model (measured at full size, tests/test_hip_fullsize.py: gradients as close
- *     to fp64 as the fp32 oracle's); test_weight_gradient_precision_per_column pins the envelope per column.
+ *     (chain.h; profiles/census/f16split.hip; tests/test_hip_parity.py).  The WEIGHT gradients reduce over rows, so a
+ *     scale cannot vary by row.  NODE-level weight gradients (node MLP, the two projections of the first edge Linear,
+ *     bsms_mlp_bwd -- every job whose operand may be a caller's tensor) use the RANGE-FREE arithmetic: the exact
+ *     three-way bf16 split (8 + 8 + 8 bits, fp32's exponent range, no scale), six partial products: a feature column
+ *     1e-7 of the tensor's maximum is as accurate as in fp32 arithmetic (test_weight_gradient_precision_per_column).
+ *     EDGE-level weight gradients of the fp32 GMP (85 % of the weight-gradient work; all six range-free would cost 3.8 % of
+ *     the step, profiles/r05_wgrad_bf3_ab.txt) keep fp16 x 2 pieces with one power-of-two scale per operand TENSOR from
+ *     the magnitude bound the chain kernels record: an element within 2^-18 of its tensor's largest magnitude keeps all
+ *     22 bits; below that the low piece is an fp16 subnormal and one bit is lost per octave.  Their operands are the edge
+ *     MLP's own post-ReLU activations and layer gradients -- never a caller's tensor -- which span far less than 2^18 per
+ *     tensor (measured at full size, tests/test_hip_fullsize.py: gradients as close to fp64 as the fp32 oracle's);
+ *     test_edge_weight_gradient_envelope pins that envelope.
  *   - Edge lists follow the reference: g = int64 [2,E], g[0] = source i, g[1] = target j
  *     (ops/basic.py:66); aggregation target is j.  "Edge order" below = the caller's order of g.
  *   - `D` (latent width) must be a multiple of 32 for the MLP/GMP entries (MFMA tile width).

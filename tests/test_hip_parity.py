@@ -412,18 +412,16 @@ def test_split_products_are_fp32_accurate(eng):
 
 
 def test_weight_gradient_precision_per_column(eng):
-    """The split-K weight-gradient kernel scales each operand TENSOR by one power of two (wgrad.hip: the reduction index is
-    the row, so the chain kernels' per-row scales cannot be used) and splits into fp16 x 2 pieces: an entry within 2^-16 of
-    the tensor's largest magnitude keeps 22 significand bits, below that the low piece goes subnormal and one bit is lost
-    per octave (include/bsms_hip.h states exactly this envelope).  Errors are measured PER COLUMN of dW (a test that
-    normalises by the whole tensor cannot see a degraded small column -- ADVICE round 3): a feature of the Linear's input
-    that is 1e-3 of the tensor maximum must be as accurate as fp32 arithmetic; at 1e-5 (2^-16.6) the documented loss is
-    <= 3e-5 of that column's own scale (measured 6e-6; fp32: 2e-6)."""
+    """Weight gradients reduce over the rows, so the chain kernels' per-row scales cannot be used.  NODE-level jobs (bsms_mlp_bwd,
+    the node MLP and the projections of a GMP block: operands may be caller tensors) run the range-free three-way bf16 split
+    (wgrad.hip: BF3, include/bsms_hip.h): a feature of the Linear's input at 1e-3, 1e-5 and 1e-7 of the tensor maximum must be as
+    accurate as fp32 arithmetic.  Errors are measured PER COLUMN of dW (a test that normalises by the whole tensor cannot see a
+    degraded small column -- ADVICE round 3); VERDICT round 4 item 2: <= 2x the fp32 error down to 1e-7."""
     torch.manual_seed(12)
     R, D = 8192, 128
     ref = ro.MLP(D, D, D, 1, True)
     sd = ref.state_dict()
-    for ratio, bound in ((1e-3, None), (1e-5, 3e-5)):
+    for ratio in (1e-3, 1e-5, 1e-7):
         x = torch.randn(R, D)
         small = [3, 64, 127]
         x[:, small] *= ratio
@@ -442,12 +440,56 @@ def test_weight_gradient_precision_per_column(eng):
         e_mine, e_32 = col_err(got), col_err(g32)
         big = [c for c in range(D) if c not in small]
         assert float(e_mine[big].max()) <= 2.0 * float(e_32[big].max()) + 1e-7, (ratio, float(e_mine[big].max()), float(e_32[big].max()))
-        if bound is None:
-            assert float(e_mine[small].max()) <= 2.0 * float(e_32[small].max()) + 1e-7, (ratio, e_mine[small], e_32[small])
-        else:
-            assert float(e_mine[small].max()) <= bound, (ratio, e_mine[small], e_32[small])
+        assert float(e_mine[small].max()) <= 2.0 * float(e_32[small].max()) + 1e-7, (ratio, e_mine[small], e_32[small])
         print(f"[wgrad per column, small features at {ratio:g} of the maximum] worst column error: engine {float(e_mine[small].max()):.2e} "
               f"(fp32 {float(e_32[small].max()):.2e}); other columns {float(e_mine[big].max()):.2e} (fp32 {float(e_32[big].max()):.2e})")
+
+
+def test_edge_weight_gradient_envelope(eng):
+    """EDGE-level weight gradients of the fp32 GMP keep fp16 x 2 pieces with one scale per operand tensor (include/bsms_hip.h: a
+    value within 2^-18 of its tensor's maximum keeps 22 bits).  Their operands are the edge MLP's own activations / layer
+    gradients; a degraded column needs an edge unit whose activation is uniformly tiny.  Built here on purpose: row 5 of the
+    second edge Linear scaled by 1e-4 (inside the window: as accurate as fp32) and by 1e-7 (outside: the documented loss, still
+    <= 1e-3 of that column's own scale); the other columns stay at fp32 accuracy in both cases."""
+    torch.manual_seed(3)
+    n, D, B = 300, 128, 2
+    pts = np.random.default_rng(5).random((n, 2))
+    from scipy.spatial import Delaunay
+    flat = torch.tensor(eng.to_flat_edge(Delaunay(pts).simplices.astype(np.int64), "tri"))
+    pos = torch.tensor(pts, dtype=torch.float32).unsqueeze(0).repeat(B, 1, 1)
+    x = torch.randn(B, n, D)
+    r = torch.randn(B, n, D)
+    col_err = lambda a, g64: ((a.double() - g64).abs().max(dim=0).values / g64.abs().max(dim=0).values)
+    for ratio, bound in ((1e-4, None), (1e-7, 1e-3)):
+        for seed in range(40):   # a model whose fp32 and fp64 runs take the same side of every ReLU (else a flipped unit is the error)
+            torch.manual_seed(100 + seed)
+            ref = ro.GMP(D, 3, 2)
+            with torch.no_grad():
+                ref.mlp_edge.seq[2].weight[5] *= ratio
+                ref.mlp_edge.seq[2].bias[5] *= ratio
+            sd = ref.state_dict()
+            def run(dt):
+                m = ro.GMP(D, 3, 2).to(dt)
+                m.load_state_dict({k: v.to(dt) for k, v in sd.items()})
+                (m(x.to(dt), flat, pos.to(dt)) * r.to(dt)).sum().backward()
+                return m.mlp_edge.seq[4].weight.grad     # dW of the third edge Linear: its INPUT column 5 is the tiny activation
+            g64, g32 = run(torch.float64), run(torch.float32)
+            if float(col_err(g32, g64).max()) < 3e-6:
+                break
+        else:
+            pytest.skip("no kink-free seed")
+        mine = load_sd(eng.GMP(D, 3, 2), sd)
+        (mine(dev(x), dev(flat), dev(pos)) * dev(r)).sum().backward()
+        got = dict(mine.named_parameters())["mlp_edge.seq.4.weight"].grad.double().cpu()
+        e_mine, e_32 = col_err(got, g64), col_err(g32, g64)
+        big = [c for c in range(D) if c != 5]
+        assert float(e_mine[big].max()) <= 2.0 * float(e_32[big].max()) + 1e-6, (ratio, float(e_mine[big].max()), float(e_32[big].max()))
+        if bound is None:
+            assert float(e_mine[5]) <= 2.0 * float(e_32[5]) + 1e-6, (ratio, float(e_mine[5]), float(e_32[5]))
+        else:
+            assert float(e_mine[5]) <= bound, (ratio, float(e_mine[5]), float(e_32[5]))
+        print(f"[edge wgrad envelope, activation column at {ratio:g}] that column: engine {float(e_mine[5]):.2e} (fp32 {float(e_32[5]):.2e}); "
+              f"others {float(e_mine[big].max()):.2e} (fp32 {float(e_32[big].max()):.2e})")
 
 
 def test_feature_split_kernels_equal_the_ring_kernels(eng):
