@@ -194,10 +194,12 @@ __device__ __forceinline__ void load_rows(f32x4 (&v)[NBX], const float* row, int
 
 // experiments (profiles/ef_timeline.py): phase stamps of chain wave 0 (slots 0-23) / gradient wave 4 (24-39), 40 slots per tile
 #ifdef BSMS_EXPERIMENTS
-#ifdef EFV_NOGSTAMP   // variant: no stamps in the gradient wave (do its stamp stores, queued behind the chain waves' gathers, stall it?)
-#define EF_STAMP_WAVES (wave == 0)
-#else
+// Stamps of the gradient wave are OFF unless -DEFV_GSTAMP: its stamp stores queue behind the chain waves' gathers and stall it for
+// ~2k cycles per tile, for which the chain waves then wait at barrier X2 -- the probe was 10 % of the tile
+#ifdef EFV_GSTAMP
 #define EF_STAMP_WAVES (wave == 0 || wave == 4)
+#else
+#define EF_STAMP_WAVES (wave == 0)
 #endif
 #define EF_STAMP(slot)                                                                                          \
   do {                                                                                                           \
@@ -412,11 +414,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (it > 0) store_g0(6);
     // ---- the next tile's endpoint rows are requested now: they land under the three gradient stages
-#ifndef EFV_LATEPF
     load_rows<NB>(ps, a.Ps + size_t(nxt.isrc) * D, g);
     load_rows<NB>(pd, a.Pd + size_t(nxt.idst) * D, g);
     fib = *reinterpret_cast<const float4*>(a.fiber + size_t(nxt.row) * 4);
-#endif
     u32x4 gb[4];
     pack(gb, gr);
     EF_STAMP(4);
@@ -446,11 +446,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } while (0)
     EF_DGRAD(W3, a2p, 0);        // Linear 3: g_2 = (W_3^T g_3) . [a_2 > 0]
     mask_pack(gb, acc, a2p);
-#ifdef EFV_LATEPF   // variant: the prefetch after the first gradient stage
-    load_rows<NB>(ps, a.Ps + size_t(nxt.isrc) * D, g);
-    load_rows<NB>(pd, a.Pd + size_t(nxt.idst) * D, g);
-    fib = *reinterpret_cast<const float4*>(a.fiber + size_t(nxt.row) * 4);
-#endif
     EF_DGRAD(W2, a1p, 1);        // Linear 2
     mask_pack(gb, acc, a1p);
     EF_DGRAD(W1, a0p, 2);        // Linear 1

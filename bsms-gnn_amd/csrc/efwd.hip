@@ -32,7 +32,10 @@ constexpr int W_BYTES = D * D * 2;            // one weight matrix as bf16 fragm
 constexpr int OFF_SIDE = 3 * W_BYTES;         // floats: fiber weights^T [4][D], then the three biases [3][D]
 constexpr int SIDE_B = 4 * D;
 constexpr int LDS_BYTES = OFF_SIDE + (4 * D + 3 * D) * 4;
-constexpr int WAVES = 16;
+#ifndef EFWD_WAVES
+#define EFWD_WAVES 16   // (variants for A/B builds: 8 = two waves per SIMD / 256 VGPRs, 12 = three / 168)
+#endif
+constexpr int WAVES = EFWD_WAVES;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
@@ -100,7 +103,7 @@ __device__ __forceinline__ EdgeRef edge_ref(unsigned row, unsigned E, float rcpE
   return EdgeRef{b, q};
 }
 
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_edge_fwd_res(EdgeFwdResArgs a) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void k_edge_fwd_res(EdgeFwdResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   // ---- prologue: the bodies of the three bf16 weight packs (chain.h: one plane, [t][lane] 16 bytes per 32-feature K chunk --
@@ -110,9 +113,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4
     constexpr int CHF = kChunkHdrFloats + NB * 256;   // floats per chunk of a one-plane pack (chain.hip: Ring<NB, 1>::CHF)
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-    for (int i = 0; i < 96 / WAVES; ++i) {
-      const int piece = uwave + i * WAVES;                // 0..95: pack l = piece / 32, chunk c = (piece / 8) & 3, 1 KB slice k = piece & 7
+    for (int piece = uwave; piece < 96; piece += WAVES) {   // 0..95: pack l = piece / 32, chunk c = (piece / 8) & 3, 1 KB slice k = piece & 7
       const int l = piece >> 5, c = (piece >> 3) & 3, k = piece & 7;
       const float* src = reinterpret_cast<const float*>(a.wp[l]) + size_t(c) * CHF + kChunkHdrFloats + k * 256 + lane * 4;
       glds16(src, __builtin_amdgcn_readfirstlane(lds0 + unsigned(piece) * 1024u));
@@ -137,14 +138,27 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4
   };
   int tile = int(blockIdx.x) * WAVES + wave;
   if (tile >= a.ntiles) return;
+#ifdef EFWD_STAGGER   // variant (A/B builds): the waves of a SIMD start a quarter of a tile apart instead of in one convoy
+  for (int i = 0; i < (wave >> 2) * EFWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
   Where nxt = locate(tile);
+#ifdef EFWD_PREFETCH   // variant (A/B builds, 8 waves): the next tile's endpoint rows are requested a tile ahead (64 registers)
+  f32x4 nps[NB], npd[NB];
+  load_rows(nps, a.Ps + (int64_t(nxt.b) * a.N + nxt.i) * D, g);
+  load_rows(npd, a.Pd + (int64_t(nxt.b) * a.N + nxt.j) * D, g);
+#endif
   for (; tile < a.ntiles; tile += stride) {
     const Where cur = nxt;
     const int64_t row = int64_t(tile) * 16 + (lane & 15);
     const bool live = row < a.R;
     f32x4 act[NB], acc[NB];
+#ifdef EFWD_PREFETCH
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { act[t] = nps[t]; acc[t] = npd[t]; }
+#else
     load_rows(act, a.Ps + (int64_t(cur.b) * a.N + cur.i) * D, g);
     load_rows(acc, a.Pd + (int64_t(cur.b) * a.N + cur.j) * D, g);
+#endif
     const float* pb = a.pos + cur.b * a.pos_bstride;
     float pi[3], pj[3];
     if (a.p == 2) {   // uniform; the common width loads whole points
@@ -184,6 +198,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4
     // ---- the three Linears, activations in registers between them
     u32x4 bb[4];
     relu_pack(bb, act);
+#ifdef EFWD_PREFETCH
+    load_rows(nps, a.Ps + (int64_t(nxt.b) * a.N + nxt.i) * D, g);   // (the indices were requested before the input stage)
+    load_rows(npd, a.Pd + (int64_t(nxt.b) * a.N + nxt.j) * D, g);
+#endif
     stage(acc, bb, lds, bias, lane);
     relu_pack(bb, acc);
     stage(acc, bb, lds + W_BYTES, bias + D, lane);

@@ -598,6 +598,11 @@ extern "C" int bsms_plan_bind_edge_weights(bsms_plan_t* p, const float* ew, bsms
   BSMS_REQUIRE(p != nullptr, BSMS_E_INVALID_ARG, "plan_bind_edge_weights: plan is null");
   if (!ew) { p->w_bound = nullptr; return BSMS_OK; }
   BSMS_REQUIRE(p->ids != nullptr, BSMS_E_INVALID_ARG, "plan_bind_edge_weights: the plan has no pool (bsms_plan_set_pool)");
+  // Already bound to ANOTHER weight tensor (the same coarse plan under a different level-0 plan): the gathered copies stay as
+  // they are -- kernels still queued on other streams and captured HIP graphs have their pointers baked in --
+  // and this tensor takes the unbound path of bsms_edge_conv (same sums in the same order, two dependent loads more per row).
+  if (p->w_bound && p->w_bound != ew) return BSMS_OK;
+  if (p->w_bound == ew) return BSMS_OK;   // nothing to do: the copies were gathered from this tensor (mesh-static weights)
   const int64_t n = std::max(p->Ek, p->Ep);
   if (n > 0) {
     hipLaunchKernelGGL(k_bind_ew, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), ew, p->k_eid, p->k_w,

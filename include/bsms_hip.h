@@ -100,7 +100,9 @@ int bsms_plan_set_pool(bsms_plan_t* plan, const int64_t* ids_host, int64_t Nk);
  * of the two pooled transitions, and every later bsms_edge_conv(..., ew, ..., pooled = 1) / U-Net call that passes the
  * SAME pointer takes compact index + weight streams instead of four levels of dependent index loads.  The caller
  * guarantees that the content of `ew` is unchanged for as long as it passes that pointer; ew = NULL unbinds.  Results
- * are bit-identical to the unbound path.  A new bsms_plan_set_pool unbinds. */
+ * are bit-identical to the unbound path.  A new bsms_plan_set_pool unbinds.  A plan already bound to ANOTHER non-null
+ * pointer keeps that binding (captured HIP graphs and kernels still queued have the gathered copies baked in); the new
+ * tensor then simply takes the unbound path.  To move a binding: bind NULL first, once nothing uses the old one. */
 int bsms_plan_bind_edge_weights(bsms_plan_t* plan, const float* ew, bsms_stream_t stream);
 int bsms_plan_destroy(bsms_plan_t* plan);
 int bsms_plan_pool_trim(void);

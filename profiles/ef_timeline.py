@@ -36,10 +36,12 @@ for lvl in [int(a) for a in sys.argv[1:]] or [0, 3]:
     d = np.diff(t, axis=1)
     life = t[:, 18] - t[:, 0]
     span = t[:, 18].max() - t[:, 0].min()
-    print(f"level {lvl}: {ntile} tiles, {len(t)} stamped; kernel span {span:.0f} ticks of s_memtime (100 MHz: {span / 100:.1f} us); tile life median {np.median(life):.0f} p90 {np.percentile(life, 90):.0f} ticks")
+    print(f"level {lvl}: {ntile} tiles, {len(t)} stamped; s_memtime ticks (~ shader clock: 18.5k ticks per tile = 126-150 us per launch of 15.3 tiles per workgroup); tile life median {np.median(life):.0f} p90 {np.percentile(life, 90):.0f} ticks")
     for k, nm in enumerate(names):
         print(f"    {nm:58s} median {np.median(d[:, k]):7.0f}  p10 {np.percentile(d[:, k], 10):7.0f}  p90 {np.percentile(d[:, k], 90):7.0f}")
     gwt = full[ok][:, 24:36]
+    if not (gwt > 0).any():   # gradient-wave stamps need a build with -DEFV_GSTAMP (they perturb the kernel: DESIGN.md 4.9)
+        continue
     gd = np.diff(gwt, axis=1)
     gn = ["X wait", "Y wait", "consume (16 tr reads x2, 32 MFMA, colsum)", "(to next)"] * 3
     print("  gradient wave 4:")

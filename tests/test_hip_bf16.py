@@ -27,7 +27,7 @@ def eng():
     return eng
 
 
-from oracle.bf16_oracle import bf16, emulate   # noqa: E402  (the documented arithmetic, stated in oracle/: VERDICT round 4 item 7)
+from oracle.bf16_oracle import bf16, emulate, restore   # noqa: E402  (the documented arithmetic, stated in oracle/: VERDICT round 4 item 7)
 
 
 def test_bf16_forward_matches_the_documented_arithmetic(eng, graphs):
@@ -62,6 +62,41 @@ def test_bf16_forward_matches_the_documented_arithmetic(eng, graphs):
         assert torch.equal(y.detach().cpu(), got)
         y.square().mean().backward()
         assert torch.isfinite(hh.grad).all() and float(hh.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_bf16_resident_kernels_three_dim_mesh_ragged_rows(eng, graphs, B):
+    """efwd.hip / efuse.hip on the shapes the airfoil tests never see: pos_dim = 3 (four fiber columns), B * E not a multiple of
+    the 16-row forward tile / the 64-row backward tile, a single sample.  Forward against the documented arithmetic
+    (oracle/bf16_oracle.py, 3e-3); every gradient against the autograd of that emulation (its casts round the gradients to
+    bf16 where the kernels do, up to the order of two roundings): 6e-2 relative L2, cosine 0.995 -- an indexing or tail bug
+    is an O(1) error in at least one tensor."""
+    es, ids = graphs.levels("surf200")
+    pos0 = graphs.t("surf200/pos").float()
+    n, D = pos0.shape[0], 128
+    assert pos0.shape[1] == 3 and (B * es[0].shape[1]) % 64 != 0
+    for depth in (0, 1):
+        torch.manual_seed(20 + depth)
+        ref = ro.BSGMP(depth, D, 3, 3)
+        mine = eng.BSGMP(depth, D, 3, 3)
+        mine.load_state_dict(ref.state_dict())
+        mine = mine.cuda()
+        mine.precision = "bf16"
+        h, pos, r = torch.randn(B, n, D), pos0.unsqueeze(0).repeat(B, 1, 1), torch.randn(B, n, D)
+        emu = emulate(ref)
+        hw = h.clone().requires_grad_(True)
+        want = emu(hw, ids[:depth], es[: depth + 1], pos)
+        (want * r).sum().backward()
+        hg = h.cuda().requires_grad_(True)
+        got = mine(hg, [i.cuda() for i in ids[:depth]], [e.cuda() for e in es[: depth + 1]], pos.cuda())
+        (got * r.cuda()).sum().backward()
+        assert rel_err(got.detach().cpu(), want.detach()) < 3e-3, (B, depth)
+        gw = {k: p.grad for k, p in emu.named_parameters() if p.grad is not None}
+        gg = {k: p.grad.cpu() for k, p in mine.named_parameters() if p.grad is not None}
+        assert set(gg) == set(gw)
+        gw["input"], gg["input"] = hw.grad, hg.grad.cpu()
+        _grads_close(gg, gw, f"surf200 p=3 B={B} depth={depth} bf16 vs emulation", l2_tol=6e-2, cos_tol=0.995)
+        restore(ref)
 
 
 def _grads_close(got, want, tag, l2_tol=5e-2, cos_tol=0.998):

@@ -198,7 +198,8 @@ def test_bound_edge_weights_transitions_bit_identical(eng, graphs, name):
     """bsms_plan_bind_edge_weights: the pooled transitions with weights gathered once into compact slot order (kept-row CSR
     for restrict, by-source CSR without the dropped targets for prolong) perform the same additions in the same order as
     the index-chasing path -- restrict, prolong and both adjoint shapes, features (D = 128, 32) and positions (D = 2, 3:
-    scalar kernel), with a fused addend; a NEW weight tensor or a re-pooled plan falls back / rebinds correctly."""
+    scalar kernel), with a fused addend; a NEW weight tensor falls back to the generic path and leaves the binding alone, a
+    re-pooled plan unbinds."""
     from bsms_gnn_amd import _abi
     from bsms_gnn_amd.ops import _stream
     es, ids = graphs.levels(name)
@@ -232,6 +233,9 @@ def test_bound_edge_weights_transitions_bit_identical(eng, graphs, name):
         _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, other.data_ptr(), _stream()), "rebind")
         _, _, half_fast = run(other, D)
         assert torch.equal(half[0], half_fast[0]) and torch.equal(half[1], half_fast[1]), D
+        torch.manual_seed(D)   # ... and a plan bound to `ew` KEEPS that binding (captured graphs have its copies baked in)
+        _, _, again = run(ew, D)
+        assert torch.equal(again[0], fast[0]) and torch.equal(again[1], fast[1]), D
     # the whole U-Net with bound weights (BSGMP.prepare binds them) == the golden output is covered by test_bsgmp_golden;
     # re-pooling unbinds: results follow the new pool
     keep = ids[0][: max(2, nk // 2)]
