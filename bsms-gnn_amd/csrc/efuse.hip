@@ -121,11 +121,16 @@ __device__ __forceinline__ void axpy_features(f32x4 (&v)[NB], const float* vec, 
 }
 // relu + round to bf16: the B operand of the next Linear (chain.hip: round_block) -- and the saved activation a_l itself
 __device__ __forceinline__ void relu_pack(u32x4 (&bb)[4], const f32x4 (&acc)[NB]) {
+  // round first, then clamp the PAIR with one packed signed-integer max: a bf16 with its sign bit set (a negative value or
+  // -0) is a negative int16, so max(., 0) is +0, and a non-negative one is left alone -- the bits of pk_bf16(max(x, 0), max(y, 0))
+  // for every non-NaN input (rounding keeps the sign), in two operations per pair instead of three
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      bb[c][v] = pk_bf16(fmaxf(acc[2 * c + (v >> 1)][2 * (v & 1)], 0.f), fmaxf(acc[2 * c + (v >> 1)][2 * (v & 1) + 1], 0.f));
+    for (int v = 0; v < 4; ++v) {
+      const unsigned w = pk_bf16(acc[2 * c + (v >> 1)][2 * (v & 1)], acc[2 * c + (v >> 1)][2 * (v & 1) + 1]);
+      asm("v_pk_max_i16 %0, %1, 0" : "=v"(bb[c][v]) : "v"(w));
+    }
 }
 __device__ __forceinline__ void pack(u32x4 (&bb)[4], const f32x4 (&acc)[NB]) {
 #pragma unroll
@@ -144,18 +149,20 @@ __device__ __forceinline__ void mask_by(f32x4 (&g)[NB], const f32x4 (&acc)[NB], 
       g[t][j] = pos ? acc[t][j] : 0.f;
     }
 }
-// mask_by + pack in one: the packed bf16 gradient pair AND-ed with an all-ones / zero half-word mask made from the packed
-// activation pair (two packed operations per PAIR instead of compare + select per element); same bits as pack(mask_by(.))
+// mask_by + pack in one: the packed bf16 gradient pair times a 0 / 1 half-word made from the packed activation pair -- an
+// INTEGER multiply of the bit pattern (x * 1 = x, x * 0 = +0): two packed operations per PAIR instead of compare + select per
+// element; the bits of pack(mask_by(.)).  (inline asm: left to itself hipcc reasons about the bf16 conversion that made `ap`
+// and emits ten compares per pair)
 __device__ __forceinline__ void mask_pack(u32x4 (&gb)[4], const f32x4 (&acc)[NB], const u32x4 (&ap)[4]) {
   const unsigned ones = 0x00010001u;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      unsigned m;   // (inline asm: left to itself hipcc reasons about the bf16 conversion that made `ap` and emits ten compares per pair)
+      unsigned m;
       asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(ap[c][v]), "s"(ones));   // 1 where a > 0 (a >= +0: bits != 0)
-      asm("v_pk_sub_u16 %0, 0, %1" : "=v"(m) : "v"(m));                      // 0xffff / 0
-      gb[c][v] = pk_bf16(acc[2 * c + (v >> 1)][2 * (v & 1)], acc[2 * c + (v >> 1)][2 * (v & 1) + 1]) & m;
+      const unsigned w = pk_bf16(acc[2 * c + (v >> 1)][2 * (v & 1)], acc[2 * c + (v >> 1)][2 * (v & 1) + 1]);
+      asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(gb[c][v]) : "v"(w), "v"(m));
     }
 }
 // acc = bias + W x   (forward direction; each accumulator takes its K chunks in the order 0..3 like chain.hip: mfma_stage_bf)
@@ -255,12 +262,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int y = 0; y < 4; ++y) dw[l][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // bias gradient: column sums of the staged G rows 16 gw .. 16 gw + 15 (lane <-> columns 2 lane, 2 lane + 1).  The 16 words are
+    // READ right after the fragments (they must be out of the staging tile before barrier X); unpacking and adding them happens
+    // after that barrier, off the path the chain waves wait on (hand-over to hand-over the chain needs 1.1k cycles, this
+    // wave's reads + MFMAs + sums took 1.4k: the chain waited 0.6k at X twice per tile)
+    unsigned cs[16];
+    auto add_sums = [&](float (&acc2)[2]) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        s0 += bf16_lo(cs[rr]);
+        s1 += bf16_hi(cs[rr]);
+      }
+      acc2[0] += s0;
+      acc2[1] += s1;
+    };
     for (int it = 0; it < my_tiles; ++it) {
 #pragma unroll
       for (int l = 2; l >= 0; --l) {
         EF_STAMP(4 * (2 - l));
         lds_barrier();   // X: the chain waves may overwrite the staging tiles (everybody is done with the previous pair)
         EF_STAMP(4 * (2 - l) + 1);
+        if (l == 2) { if (it > 0) add_sums(db[0]); }   // the previous hand-over's rows
+        else add_sums(db[l + 1]);
         lds_barrier();   // Y: (G_{l+1}, A_l) of this tile are staged
         EF_STAMP(4 * (2 - l) + 2);
 #pragma unroll
@@ -275,20 +299,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int y = 0; y < 4; ++y) dw[l][x][y] = mma(gf[x], af[y], dw[l][x][y]);
         }
-        // bias gradient: column sums of the staged G rows 16 gw .. 16 gw + 15 (lane <-> columns 2 lane, 2 lane + 1)
-        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int row = 16 * gw + rr;
-          const unsigned u = *reinterpret_cast<const unsigned*>(GST + piece_off(row, lane >> 1) + 4 * (lane & 1));
-          s0 += bf16_lo(u);
-          s1 += bf16_hi(u);
-        }
-        db[l][0] += s0;
-        db[l][1] += s1;
+        for (int rr = 0; rr < 16; ++rr)
+          cs[rr] = *reinterpret_cast<const unsigned*>(GST + piece_off(16 * gw + rr, lane >> 1) + 4 * (lane & 1));
         EF_STAMP(4 * (2 - l) + 3);
       }
     }
+    if (my_tiles > 0) add_sums(db[0]);
     // partial results of this workgroup: dW[l][n][k] (lane holds rows n = 64 gi + 16 x + 4 g + j, column k = 64 gj + 16 y + r)
     float* part = a.part + size_t(blockIdx.x) * (DW_FLOATS + DB_FLOATS);
 #pragma unroll
@@ -393,24 +410,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     relu_pack(a2p, acc);
     EF_STAMP(3);
     if (it > 0) store_g0(4);
-    // ---- LayerNorm backward (no affine): g_3 = rstd * (dy - mean(dy) - y * mean(dy * y))   (chain.hip: k_chain_bwd)
+    // ---- LayerNorm backward (no affine): g_3 = rstd * (dy - mean(dy) - y * mean(dy * y))   (chain.hip: k_chain_bwd), written as
+    // two fused multiply-adds per element, g_3 = fma(-c1, y, fma(c0, dy, c2)) with c0 = rstd, c1 = rstd * mean(dy y),
+    // c2 = -rstd * mean(dy): a quarter of the VALU work of the literal form (the chain waves are issue-bound: every VALU
+    // operation delays the MFMAs behind it; the packed ReLU alone was worth 11 % of this kernel)
     f32x4 gr[NB];
     {
-      const float m1 = row_sum(dy) * (1.f / D);
-      float s2 = 0.f;
+      f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
         act[t] = f32x4{bf16_lo(yb[t][0]), bf16_hi(yb[t][0]), bf16_lo(yb[t][1]), bf16_hi(yb[t][1])};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s2 = fmaf(dy[t][j], act[t][j], s2);
+        const f32x2 d0 = {dy[t][0], dy[t][1]}, d1 = {dy[t][2], dy[t][3]}, y0 = {act[t][0], act[t][1]}, y1 = {act[t][2], act[t][3]};
+        sa += d0 + d1;
+        sb = __builtin_elementwise_fma(d0, y0, sb);
+        sb = __builtin_elementwise_fma(d1, y1, sb);
       }
-      s2 = group_sum(s2);
-      const float m2 = s2 * (1.f / D);
-      const float keep = cur.live ? 1.f : 0.f;   // rows past the end contribute nothing to dW / db
+      const float m1 = group_sum(sa[0] + sa[1]) * (1.f / D);
+      const float m2 = group_sum(sb[0] + sb[1]) * (1.f / D);
+      const float c0 = cur.live ? rstd : 0.f;   // rows past the end contribute nothing to dW / db
+      const float c1 = c0 * m2, c2 = -(c0 * m1);
+      const f32x4 v0 = {c0, c0, c0, c0}, v1 = {-c1, -c1, -c1, -c1}, v2 = {c2, c2, c2, c2};
 #pragma unroll
-      for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gr[t][j] = keep * (rstd * (dy[t][j] - m1 - act[t][j] * m2));
+      for (int t = 0; t < NB; ++t) gr[t] = __builtin_elementwise_fma(v1, act[t], __builtin_elementwise_fma(v0, dy[t], v2));
     }
     if (it > 0) store_g0(6);
     // ---- the next tile's endpoint rows are requested now: they land under the three gradient stages
@@ -449,23 +470,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     EF_DGRAD(W2, a1p, 1);        // Linear 2
     mask_pack(gb, acc, a1p);
     EF_DGRAD(W1, a0p, 2);        // Linear 1
-    mask_by(gr, acc, a0p);
 #undef EF_DGRAD
     EF_STAMP(17);
-    // ---- g_0 (bf16: input of the scatter / fiber-gradient kernel) is kept packed for the deferred stores + its magnitude bound
-    {
-      if (a.gmax) {   // uniform (null when nobody consumes the bound: the projections' weight gradients run range-free, gmp.hip)
-        float m = 0.f;
+    // ---- g_0 (bf16: input of the scatter / fiber-gradient kernel) is kept packed for the deferred stores
+    if (a.gmax) {   // uniform: somebody wants its magnitude bound (A/B builds with fp16 x 2 projections' weight gradients, gmp.hip)
+      mask_by(gr, acc, a0p);
+      float m = 0.f;
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-          m = fmaxf(fmaxf(m, fabsf(gr[t][0])), fabsf(gr[t][1]));
-          m = fmaxf(fmaxf(m, fabsf(gr[t][2])), fabsf(gr[t][3]));
-        }
-        gmax = fmaxf(gmax, m);
+      for (int t = 0; t < NB; ++t) {
+        m = fmaxf(fmaxf(m, fabsf(gr[t][0])), fabsf(gr[t][1]));
+        m = fmaxf(fmaxf(m, fabsf(gr[t][2])), fabsf(gr[t][3]));
       }
+      gmax = fmaxf(gmax, m);
       pack(g0p, gr);
-      g0row = cur.srow;
+    } else {
+      mask_pack(g0p, acc, a0p);
     }
+    g0row = cur.srow;
     EF_STAMP(18);
     cur = nxt;
   }

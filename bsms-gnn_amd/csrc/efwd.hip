@@ -72,11 +72,16 @@ __device__ __forceinline__ void axpy_features(f32x4 (&v)[NB], const float* vec, 
 }
 // relu, then the bf16 rounding that makes the B operand of the next Linear (chain.hip: relu_into + round_block)
 __device__ __forceinline__ void relu_pack(u32x4 (&bb)[4], const f32x4 (&acc)[NB]) {
+  // round first, then clamp the PAIR with one packed signed-integer max: a bf16 with its sign bit set (a negative value or
+  // -0) is a negative int16, so max(., 0) is +0, and a non-negative one is left alone -- the bits of pk_bf16(max(x, 0), max(y, 0))
+  // for every non-NaN input (rounding keeps the sign), in two operations per pair instead of three
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      bb[c][v] = pk_bf16(fmaxf(acc[2 * c + (v >> 1)][2 * (v & 1)], 0.f), fmaxf(acc[2 * c + (v >> 1)][2 * (v & 1) + 1], 0.f));
+    for (int v = 0; v < 4; ++v) {
+      const unsigned w = pk_bf16(acc[2 * c + (v >> 1)][2 * (v & 1)], acc[2 * c + (v >> 1)][2 * (v & 1) + 1]);
+      asm("v_pk_max_i16 %0, %1, 0" : "=v"(bb[c][v]) : "v"(w));
+    }
 }
 // acc = bias + W x: every accumulator takes its K chunks in the order 0..3 (chain.hip: mfma_stage_bf)
 __device__ __forceinline__ void stage(f32x4 (&acc)[NB], const u32x4 (&bb)[4], const char* W, const float* bias, int lane) {
@@ -138,27 +143,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   };
   int tile = int(blockIdx.x) * WAVES + wave;
   if (tile >= a.ntiles) return;
-#ifdef EFWD_STAGGER   // variant (A/B builds): the waves of a SIMD start a quarter of a tile apart instead of in one convoy
-  for (int i = 0; i < (wave >> 2) * EFWD_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
-#endif
   Where nxt = locate(tile);
-#ifdef EFWD_PREFETCH   // variant (A/B builds, 8 waves): the next tile's endpoint rows are requested a tile ahead (64 registers)
-  f32x4 nps[NB], npd[NB];
-  load_rows(nps, a.Ps + (int64_t(nxt.b) * a.N + nxt.i) * D, g);
-  load_rows(npd, a.Pd + (int64_t(nxt.b) * a.N + nxt.j) * D, g);
-#endif
   for (; tile < a.ntiles; tile += stride) {
     const Where cur = nxt;
     const int64_t row = int64_t(tile) * 16 + (lane & 15);
     const bool live = row < a.R;
     f32x4 act[NB], acc[NB];
-#ifdef EFWD_PREFETCH
-#pragma unroll
-    for (int t = 0; t < NB; ++t) { act[t] = nps[t]; acc[t] = npd[t]; }
-#else
     load_rows(act, a.Ps + (int64_t(cur.b) * a.N + cur.i) * D, g);
     load_rows(acc, a.Pd + (int64_t(cur.b) * a.N + cur.j) * D, g);
-#endif
     const float* pb = a.pos + cur.b * a.pos_bstride;
     float pi[3], pj[3];
     if (a.p == 2) {   // uniform; the common width loads whole points
@@ -198,10 +190,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // ---- the three Linears, activations in registers between them
     u32x4 bb[4];
     relu_pack(bb, act);
-#ifdef EFWD_PREFETCH
-    load_rows(nps, a.Ps + (int64_t(nxt.b) * a.N + nxt.i) * D, g);   // (the indices were requested before the input stage)
-    load_rows(npd, a.Pd + (int64_t(nxt.b) * a.N + nxt.j) * D, g);
-#endif
     stage(acc, bb, lds, bias, lane);
     relu_pack(bb, acc);
     stage(acc, bb, lds + W_BYTES, bias + D, lane);

@@ -69,8 +69,8 @@ def test_bf16_resident_kernels_three_dim_mesh_ragged_rows(eng, graphs, B):
     """efwd.hip / efuse.hip on the shapes the airfoil tests never see: pos_dim = 3 (four fiber columns), B * E not a multiple of
     the 16-row forward tile / the 64-row backward tile, a single sample.  Forward against the documented arithmetic
     (oracle/bf16_oracle.py, 3e-3); every gradient against the autograd of that emulation (its casts round the gradients to
-    bf16 where the kernels do, up to the order of two roundings): 6e-2 relative L2, cosine 0.995 -- an indexing or tail bug
-    is an O(1) error in at least one tensor."""
+    bf16 where the kernels do, up to the order of two roundings): 1e-2 relative L2 for one block, 1e-1 three blocks deep -- an
+    indexing or tail bug is an O(1) error in at least one tensor."""
     es, ids = graphs.levels("surf200")
     pos0 = graphs.t("surf200/pos").float()
     n, D = pos0.shape[0], 128
@@ -95,7 +95,9 @@ def test_bf16_resident_kernels_three_dim_mesh_ragged_rows(eng, graphs, B):
         gg = {k: p.grad.cpu() for k, p in mine.named_parameters() if p.grad is not None}
         assert set(gg) == set(gw)
         gw["input"], gg["input"] = hw.grad, hg.grad.cpu()
-        _grads_close(gg, gw, f"surf200 p=3 B={B} depth={depth} bf16 vs emulation", l2_tol=6e-2, cos_tol=0.995)
+        # measured: one block 3.6e-3 / cosine 0.99999; three blocks deep 4.9e-2 / 0.9988 (the emulation rounds a gradient AFTER
+        # the product with W^T, the kernels BEFORE it, and the difference compounds through the blocks)
+        _grads_close(gg, gw, f"surf200 p=3 B={B} depth={depth} bf16 vs emulation", l2_tol=1e-2 if depth == 0 else 1e-1, cos_tol=0.9999 if depth == 0 else 0.995)
         restore(ref)
 
 
