@@ -143,10 +143,13 @@ static const int g_edge_fused = env_fused();
 #else
 constexpr int g_edge_fused = 1;
 #endif
-// Weight gradients of the NODE-level Linears (node MLP, the two projections, the encoder / decoder MLPs): the range-free
-// three-way bf16 split (wgrad.hip: BF3, six products) instead of fp16 x 2 pieces with one scale per tensor -- their operands
-// include caller-supplied tensors whose columns may differ by any factor, and they
-// are ~15 % of the weight-gradient work.  Experiment builds can switch back for A/B runs (BSMS_NODE_BF3=0).
+// Weight-gradient jobs whose `A` operand is a CALLER's tensor -- every job of bsms_mlp_bwd, and in a GMP block the x half of the
+// first node Linear and the two projections (A = x) -- run the range-free three-way bf16 split (wgrad.hip: BF3, six products)
+// instead of fp16 x 2 pieces with one scale per tensor: a caller's columns may differ by any factor (VERDICT
+// round 4 item 2).  The other node-level jobs multiply the block's own post-ReLU activations / LayerNorm-bounded sums, like
+// the edge-level ones, and keep the three-product arithmetic: all node-level jobs range-free measured 0 on the airfoil step
+// but -2.6 % / -7.5 % on the cylinder steps (dense / block-diagonal), where the side lane is co-critical
+// (profiles/r05_node_bf3_ab.txt).  Experiment builds: BSMS_NODE_BF3 = 0 none / 1 this / 2 all node-level jobs.
 #ifdef BSMS_EXPERIMENTS
 static int env_node_bf3() { const char* e = getenv("BSMS_NODE_BF3"); return e ? atoi(e) : 1; }
 static const int g_node_bf3 = env_node_bf3();
@@ -337,7 +340,7 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     }
     a.y = out; a.yln = sv.n_yln; a.rstd = sv.n_rstd; a.resid = x; a.resid2 = resid2;
     a.bf16 = bfn;
-    if (!g_node_bf3) {   // (A/B only: bounds for the fp16 x 2 weight-gradient arithmetic)
+    if (g_node_bf3 < 2) {   // bounds for the fp16 x 2 weight-gradient jobs of the node Linears
       if (training && !bfn) for (int st = 0; st <= H; ++st) a.amax[st] = sv.bound + size_t(8 + st) * kBoundWidth;
       else if (training) a.amax[0] = sv.bound + size_t(8) * kBoundWidth;   // BSMS_BF16_NODES: only [x, aggr] feed an fp32 weight-gradient job
     }
@@ -410,7 +413,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     a.wh1 = reinterpret_cast<const float4*>(sv.n_w0at);
     a.dx = grad_x; a.dx2 = wk.daggr; a.dres = grad_out;
     a.bf16 = bfn;
-    if (!g_node_bf3) {
+    if (g_node_bf3 < 2) {
       if (!bfn) for (int k = 0; k <= H; ++k) a.gmax[k] = sv.bound + size_t(24 + k) * kBoundWidth;
       else a.gmax[H] = sv.bound + size_t(24 + H) * kBoundWidth;   // BSMS_BF16_NODES: only gN[0] (fp32) feeds an fp32 weight-gradient job
     }
@@ -479,13 +482,17 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0, bd(16 + (H - l)), bd(l - 1));
       jobs[nj - 1].bf16 = bf;
     }
-    auto nbd = [&](int slot) -> const float* { return g_node_bf3 ? nullptr : bd(slot); };   // node level: no bounds = the range-free arithmetic
+    // no bounds = the range-free arithmetic: the job over the caller's x (g_node_bf3 >= 1), every node-level job (2)
+    auto nbd = [&](int slot, int level) -> const float* { return g_node_bf3 >= level ? nullptr : bd(slot); };
     for (int l = 1; l <= H; ++l) {   // node Linears 1..H: bf16 tensors in BSMS_BF16_NODES
-      add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0, nbd(24 + (H - l)), nbd(8 + l));
+      add_job(wk.gN[l], sv.n_act[l - 1], gn[2 * l], gn[2 * l + 1], B * N, (int)D, 0, nbd(24 + (H - l), 2), nbd(8 + l, 2));
       jobs[nj - 1].bf16 = bfn;
     }
-    add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0, nbd(24 + H), nbd(8));
-    add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D, nbd(24 + H), nbd(8));
+    // the job over the caller's x (with the first node Linear's bias gradient): range-free arithmetic = another launch, so
+    // at level 1 it rides in lane 2's launch with the two projections (all three range-free) and this lane stays ONE launch of
+    // three-product jobs -- two launches here cost the cylinder steps 1.6 % / 6 % (side lane co-critical, r05_node_bf3_ab.txt)
+    if (g_node_bf3 != 1) add_job(wk.gN[0], x, gn[0], gn[1], B * N, int(2 * D), 0, nbd(24 + H, 1), nbd(8, 1));
+    add_job(wk.gN[0], sv.aggr, gn[0], nullptr, B * N, int(2 * D), (int)D, nbd(24 + H, 2), nbd(8, 2));
     if ((rc = launch_wgrad((int)D, jobs, nj, wk.wg, ws))) return rc;
   }
   // a second side stream takes the remaining weight gradients of the first edge Linear (fiber columns + bias now,
@@ -527,7 +534,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   }
   if (nwg > 0 && (rc = launch_small_reduce(sw, wk.sw, nwg, s2))) return rc;
   {
-    WgradJob jobs[2] = {};
+    WgradJob jobs[3] = {};
     auto set = [&](WgradJob& j, const float* G, int col0) {
       j.G = G; j.A = x; j.dW = ge[0]; j.db = nullptr; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = ldE0; j.col0 = col0; j.bf16 = 0;
       // dPs / dPd are sums of at most max-degree rows of gE[0]; x is covered by the joint bound of the node chain's input
@@ -538,7 +545,13 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     set(jobs[1], wk.dPd, int(p + 1 + D));
     jobs[0].g_mul = float(std::max<int64_t>(plan->max_out_degree, 1));   // scatter by source
     jobs[1].g_mul = float(std::max<int64_t>(plan->max_in_degree, 1));    // scatter by target
-    if ((rc = launch_wgrad((int)D, jobs, 2, wk.wg2, s2))) return rc;
+    int nj2 = 2;
+    if (g_node_bf3 == 1) {   // + the x half of the first node Linear (see above)
+      WgradJob& j = jobs[nj2++];
+      j.G = wk.gN[0]; j.A = x; j.dW = gn[0]; j.db = gn[1]; j.R = B * N; j.ldg = (int)D; j.lda = (int)D; j.ldw = int(2 * D); j.col0 = 0;
+      j.bf16 = 0; j.g_bound = j.a_bound = nullptr; j.g_mul = j.a_mul = 1.f;
+    }
+    if ((rc = launch_wgrad((int)D, jobs, nj2, wk.wg2, s2))) return rc;
   }
   // grad_x += dPs Wi + dPd Wj
   {

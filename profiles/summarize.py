@@ -53,6 +53,8 @@ def main():
                 "k_rowsum_pair": ("both scatters of gE[0] (by source + by target) in one launch", [f"L{l}" for l in unet]),
                 "k_edge_fwd<8": ("edge MLP forward chain (pipelined kernel; <8, RB, save>: RB row blocks per wave)", [f"L{l}" for l in unet]),
                 "k_edge_bwd<8": ("edge MLP backward chain (pipelined kernel)", [f"L{l}" for l in unet]),
+                "k_edge_fused_bwd": ("fused edge backward of the bf16 precisions (efuse.hip: recompute + dgrad + dW on chip)", [f"L{l}" for l in unet]),
+                "k_edge_fwd_res": ("edge MLP forward of the bf16 precisions with LDS-resident weights (efwd.hip)", [f"L{l}" for l in unet]),
                 "k_chain_fwd<8, 3, 0": ("edge MLP forward chain (IN_EDGE, OUT_LN; builds before the pipelined kernels)", [f"L{l}" for l in unet]),
                 "k_chain_bwd<8, 1, 0": ("edge MLP backward chain (G_EDGE_LN; builds before the pipelined kernels)", [f"L{l}" for l in unet]),
                 "k_chain_fwd<8, 1, 0": ("node MLP forward chain (IN_ROWS2, OUT_LN)", [f"L{l}" for l in unet]),
@@ -76,6 +78,12 @@ def main():
         if key.startswith("k_rowsum_pair"):
             w = 2 * B * e * D * S + 2 * B * n * D * S
             return f"{w / 1e6:.1f} MB -> {w / t / 1e12:.2f} TB/s = {w / t / HBM_PEAK:.2f} of HBM peak"
+        if key.startswith("k_edge_fwd_res") or key.startswith("k_edge_fused_bwd"):   # bf16 precisions: ONE product per fragment pair
+            units = 3 if "fwd" in key else 8                      # Linears: forward 3; backward 2 recomputed + 3 dgrad + 3 dW
+            fl = 2 * B * e * units * D * D
+            by = B * e * (D * 2 + 20) * (1 if "fwd" in key else 2)  # y (bf16) + fiber + rstd written / read, g0 (bf16) written
+            return (f"{fl / 1e9:.1f} GFLOP -> {fl / t / 1e12:.0f} TF/s = {fl / t / (3 * SPLIT_PEAK):.3f} of the dense bf16 peak; "
+                    f"{by / 1e6:.0f} MB of edge rows -> {by / t / 1e12:.2f} TB/s = {by / t / HBM_PEAK:.2f} of HBM peak")
         if key.startswith("k_chain_fwd<8, 3") or key.startswith("k_chain_bwd<8, 1") or key.startswith("k_edge_"):
             fl = 2 * B * e * 3 * D * D
             by = B * e * D * S * (4 if "fwd" in key else 5)   # fwd: 3 saved activations + messages; bwd: 4 layer gradients + y

@@ -24,7 +24,8 @@ Tolerances (BASELINE.json north_star: 1e-5 relative fp32)
     i.e. the engine's distance to the exact gradient has the same distribution over the parameter tensors as the
     reference's own fp32 path.  (Rounds 1-3 allowed 3x / 2x / 2x; the measured ratios are 1.0-1.4 on the BASELINE
     configurations.  The depth-7 strip at B=4 -- few rows per coarse level, so few independent kink events -- measured a
-    median ratio of 1.63 and keeps 2x for (b).)  A per-tensor ratio is not meaningful (which tensors a near-zero ReLU input lands in is
+    median ratio of 1.63 in round 4 and 0.22 in round 5 -- the oracle's own fp32 run moves with the host's thread count --
+    and keeps 2x for (b).)  A per-tensor ratio is not meaningful (which tensors a near-zero ReLU input lands in is
     random for both implementations), and the factors allow for the fact that ONE flipped mask perturbs the gradient
     of every layer upstream of it, so the per-tensor errors of a run are strongly correlated (few independent events).
     Measured on MI355X (gpu | cpu32, worst / median): airfoil B=8 9.4e-5 / 1.0e-5 | 9.3e-5 / 8.1e-6; cylinder B=8
@@ -171,4 +172,7 @@ def test_airfoil_depth7_reference_default(eng):
     w, mesh = strip_mesh(327, 16, 7)
     r = run_config(eng, "airfoil", 4, "dense", mesh=mesh, cfg=w)
     assert len(r["levels"]) == 8 and r["levels"][0][0] == 5232 and r["levels"][-1][0] >= 2
+    # median factor 2.0 stays: the ratio is a property of WHICH near-zero ReLU inputs flip in the two fp32 runs, and the oracle's
+    # run depends on the host (CPU thread count -> summation order): measured 1.63 in round 4 (5.7e-5 vs 3.5e-5) and 0.22 in
+    # round 5 (2.4e-5 vs 1.07e-4) on two boxes of the pool, same GPU arithmetic for this configuration's dominant tensors
     check(r, "airfoil-sized strip B=4 L=7 (reference default depth)", f_median=2.0)
