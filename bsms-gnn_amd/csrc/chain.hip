@@ -361,14 +361,14 @@ __device__ __forceinline__ void store_mask_bits(const f32x4 (&v)[NB], float* act
 #pragma unroll
   for (int w = 0; w < W; ++w) {
     unsigned m = 0;
+    constexpr int N = (4 * NB < 32) ? 4 * NB : 32;
 #pragma unroll
-    for (int k = 0; k < 32 && 32 * w + k < 4 * NB; ++k) {
+    for (int k = N - 1; k >= 0; --k) {   // highest element first: every step shifts the word left by one and appends a bit
       const int e = 32 * w + k;
-      // `v` is a post-ReLU activation (>= +0): it is positive iff its bit pattern is non-zero -- min + shift-or, two
-      // operations per element instead of compare + select + or
-      unsigned b;
-      asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(v[e >> 2][e & 3])));   // (hipcc turns min(x, 1) into compare + select)
-      m |= b << k;
+      // `v` is a post-ReLU activation (>= +0): it is positive iff its bit pattern is non-zero, i.e. iff 0 - bits has its top
+      // bit set (bits <= 0x7fffffff).  v_sub + v_alignbit((m : 0 - bits) >> 31) = two operations per element and no inline asm
+      // (round 4 used v_min_u32 in inline asm + shift + or: hipcc puts an s_nop behind every asm statement, 3.3 issue slots)
+      m = __builtin_amdgcn_alignbit(m, 0u - __float_as_uint(v[e >> 2][e & 3]), 31);
     }
     bits[w] = m;
   }
@@ -817,12 +817,17 @@ __device__ __forceinline__ void mfma_stage(f32x4 (&acc)[NB], const f32x4 (&act)[
   }
 }
 
+// ReLU as ONE integer operation per element: a float with its sign bit set (negative, -0) is a negative int32, so
+// max(bits, 0) is +0 and everything else is left alone -- the bits of fmaxf(x, 0) for every non-NaN input, and a NaN
+// stays a NaN as in torch.relu (fmaxf would return 0).  fmaxf compiles to TWO v_max_f32 per element whenever hipcc cannot prove
+// its input canonical (the un-scaled accumulators: 64 operations per stage in k_edge_fwd; same-box effect on the fp32 step: none,
+// profiles/r05_f32_valu.txt -- kept for the NaN semantics and the halved instruction count).
 template <int NB>
 __device__ __forceinline__ void relu_into(f32x4 (&dst)[NB], const f32x4 (&srcv)[NB]) {
 #pragma unroll
   for (int t = 0; t < NB; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[t][r] = fmaxf(srcv[t][r], 0.f);
+    for (int r = 0; r < 4; ++r) dst[t][r] = __int_as_float(max(__float_as_int(srcv[t][r]), 0));
 }
 
 // v += scale * vec (vec in lane feature order)
@@ -1304,7 +1309,7 @@ __global__ __launch_bounds__(256) void k_fs_fwd(ChainFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) own[i][r] = fmaxf(own[i][r], 0.f);
+      for (int r = 0; r < 4; ++r) own[i][r] = __int_as_float(max(__float_as_int(own[i][r]), 0));
     fs_save(a.store_in, own, a.R, row, live, w, lane, !(a.store_mode & 4));
     if (a.nstage == 0) return;
   }
@@ -1345,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_fs_fwd(ChainFwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) own[i][r] = fmaxf(acc[i][r], 0.f);
+        for (int r = 0; r < 4; ++r) own[i][r] = __int_as_float(max(__float_as_int(acc[i][r]), 0));
     }
     if (last) return false;
     fs_save(a.store[l], own, a.R, row, live, w, lane, !(a.store_mode & 4));
@@ -1784,13 +1789,12 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
       asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(o.l[v]) : "v"(x0), "v"(rs[rb].s), "v"(o.h[v]));
       asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(o.l[v]) : "v"(x1), "v"(rs[rb].s), "v"(o.h[v]));
     }
-  } else if (SAVE && MASK) {   // ---- M steps
+  } else if (SAVE && MASK) {   // ---- M steps: highest element first, one shift-and-append per element (store_mask_bits)
     constexpr int EPS = (4 * NB + 7) / 8;
 #pragma unroll
-    for (int e = ss * EPS; e < (ss + 1) * EPS && e < 4 * NB; ++e) {
-      unsigned b;
-      asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(act[rb][e >> 2][e & 3])));   // post-ReLU value: positive iff non-zero bits
-      mword[rb][e >> 5] |= b << (e & 31);
+    for (int i = ss * EPS; i < (ss + 1) * EPS && i < 4 * NB; ++i) {
+      const int e = 4 * NB - 1 - i;
+      mword[rb][e >> 5] = __builtin_amdgcn_alignbit(mword[rb][e >> 5], 0u - __float_as_uint(act[rb][e >> 2][e & 3]), 31);
     }
     if (ss == 7) {
       unsigned* bits = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(bits_base) + moff[rb]);
