@@ -1,13 +1,13 @@
 #!/bin/bash
 # HBM bytes and matrix-pipe busy cycles of the training step by kernel family (PMC passes on their own, as the guide
-# prescribes):  gpurun -- 'bash profiles/step_pmc.sh'   -> gpurun_out/step_pmc/summary.txt
+# prescribes):  gpurun -- 'bash profiles/step_pmc.sh'   -> gpurun_out/step_pmc/summary.txt      (DTYPE=bf16 for the bf16 step)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 out=gpurun_out/step_pmc
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   tag=$(echo $c | cut -d' ' -f1)
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$tag -o x -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > $out/$tag.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$tag -o x -- python bench.py --dtype ${DTYPE:-f32} --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-other-lines > $out/$tag.log 2>&1
 done
 python - <<'PY' | tee gpurun_out/step_pmc/summary.txt
 import csv, glob, re, collections
