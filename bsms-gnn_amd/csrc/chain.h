@@ -221,13 +221,16 @@ size_t small_wgrad_work_bytes(int D);
 size_t small_wgrad_work_bytes_rows(int D, int64_t workers);   // sized for the fused pair kernel: one block per 256 / (D/4) row workers
 int launch_small_wgrad(const SmallWgradArgs& a, void* work, hipStream_t s);
 
-// efuse.hip: the fused backward of the edge MLP in the bf16 precisions (D = 128, hidden = 3): forward recompute of a_1, a_2 + LayerNorm
+// efuse.hip: the fused backward of the edge MLP in the bf16 precisions (D = 128, hidden = 3): forward recompute + LayerNorm
 // backward + dgrad chain + the weight / bias gradients of Linears 1..3 accumulated on chip; g_0 leaves as bf16
 struct EdgeFusedBwdArgs {
   int64_t R;                  // B * E edge rows (plan order)
   int32_t E, N;
-  const int32_t* dst;         // plan-order targets
-  const void* a0;             // [R, D] bf16 in operand order (EdgeFwdResArgs::a0_out): the forward's a_0, bit for bit
+  const int32_t *src, *dst;   // plan-order endpoints
+  const float *Ps, *Pd;       // the forward's node projections [B*N, D] (kept in the saved blob in this mode)
+  const float* fiber;         // [R, 4]: the fiber rows the forward kept
+  const float* wft;           // fiber weights^T [p+1][D]
+  int p;
   const float4* wr[3];        // PACK_ROWS_BF16 images of edge Linears 1..3 (the rounding of the forward's packs)
   const float* b[3];          // their biases (fp32 parameters)
   const float* dy;            // [B*N, D] gradient of the aggregate (gathered by target)
@@ -260,9 +263,6 @@ struct EdgeFwdResArgs {
   void* y;                    // [R, D] bf16 messages
   float* rstd;                // [R] (nullable: inference)
   float* fiber_out;           // [R, 4] (nullable: inference)
-  void* a0_out;               // [R, D] bf16, OPERAND order (nullable: inference): the activation after the input stage exactly as it
-                              // enters Linear 1 -- per row four 64-byte groups (K chunk c), in each the 16 bytes of lane group g =
-                              // features 32 c + 4 g + {0..3}, 32 c + 16 + 4 g + {0..3} (chain.h K-slot map); efuse.hip loads it back
   int ntiles;                 // filled by the launcher
 };
 bool edge_fwd_res_supported(int64_t D, int H, int64_t p, int precision);

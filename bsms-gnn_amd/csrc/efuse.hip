@@ -1,19 +1,17 @@
 // Fused backward of the edge MLP for the bf16 precisions (BSMS_BF16 / BSMS_BF16_NODES), D = 128, hidden = 3:
-// forward RECOMPUTE of a_1, a_2 + LayerNorm backward + dgrad chain + the weight gradients of the three D x D Linears in ONE kernel.
+// forward RECOMPUTE + LayerNorm backward + dgrad chain + the weight gradients of the three D x D Linears in ONE kernel.
 // Reference arithmetic: src/ops/basic.py:6-23 (MLP), :90-94 (edge message + scatter), under trainer/trainer.py:146-147.
 //
 // Why: the unfused backward wrote every layer gradient gE[1..H] and the forward every
 // activation a_0..a_{H-1} to HBM only so that a separate split-K kernel could read them back: at airfoil level 0 that is
 // 192 MB + 192 MB written and 384 MB re-read per block for tensors whose values the chain kernels had in registers.  Here
-// nothing of that touches HBM: the forward saves only the messages y, rstd, the 16-byte fiber of every edge and a_0 as the
-// packed bf16 operand of Linear 1 (efwd.hip; the first version re-created a_0 too -- two row gathers of 512 bytes per edge and
-// the whole input stage: a third of a tile's time went into ISSUING those loads); this kernel re-creates
-// a_1, a_2 on the matrix cores (two extra Linears: the matrix pipe was 20 % busy), runs the gradient chain, and accumulates
-// dW_l += G_l^T A_{l-1} on chip.
+// nothing of that touches HBM: the forward saves only the messages y, rstd and the 16-byte fiber of every edge; this
+// kernel re-creates a_0 (gather of the two node projections + fiber), a_1, a_2 on the matrix cores (two extra Linears:
+// the matrix pipe was 20 % busy), runs the gradient chain, and accumulates dW_l += G_l^T A_{l-1} on chip.
 //
 // Shape of a workgroup (512 threads, one per CU, persistent over 64-row tiles):
 //   waves 0-3  "chain" waves: 16 edge rows each in the chain layout of chain.h (lane <-> row, features in registers);
-//              per tile: a_0 (loaded) -> a_1 -> a_2 (bit-identical to the forward kernel: same operands, same product
+//              per tile: gather -> a_0 -> a_1 -> a_2 (bit-identical to the forward kernel: same operands, same product
 //              order), LayerNorm backward -> g_3, then three times { hand (G_l, A_{l-1}) of its 16 rows to LDS; dgrad
 //              through W_l, masked by a_{l-1} > 0 }, finally g_0 -> HBM as bf16 (the scatter kernel's input).
 //   waves 4-7  "gradient" waves: hold ALL of dW_1..3 for the workgroup's rows in registers (3 x 128 x 128 fp32 = 192
@@ -26,7 +24,7 @@
 // [n][k] with a 288-byte pitch and an 8-byte-piece XOR swizzle (piece ^= (row >> 2) & 3).  ONE copy serves both
 // directions: the forward A-fragments are two ds_read_b64 per lane, the transposed (dgrad) fragments two
 // ds_read_b64_tr_b16 -- the K-slot -> feature map of chain.h is exactly what the transposing read delivers.  No loader
-// wave, no ring, no chunk barriers.  LDS: 3 x 36 KB weights + 2 x 18 KB staging + 1 KB of biases = 145 KB.
+// wave, no ring, no chunk barriers.  LDS: 3 x 36 KB weights + 2 x 18 KB staging + 3 KB side tables = 147 KB.
 // Determinism: every workgroup writes its partial dW / db once; k_ef_reduce sums them in a fixed order (no atomics).
 #include "chain.h"
 
@@ -51,7 +49,7 @@ constexpr int W_BYTES = D * ROWB;             // one weight matrix
 constexpr int ST_ROWS = 64;                   // rows of a tile = 4 chain waves x 16
 constexpr int ST_BYTES = ST_ROWS * ROWB;
 constexpr int OFF_G = 3 * W_BYTES, OFF_A = OFF_G + ST_BYTES, OFF_SIDE = OFF_A + ST_BYTES;
-constexpr int SIDE_B1 = 0, SIDE_B2 = D * 4;   // the biases of the two recomputed Linears
+constexpr int SIDE_WFT = 0, SIDE_B1 = 4 * D * 4, SIDE_B2 = SIDE_B1 + D * 4;
 constexpr int LDS_BYTES = OFF_SIDE + SIDE_B2 + D * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 static_assert(W_BYTES % 1024 == 0, "whole LDS-DMA pieces");
@@ -238,6 +236,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   {
     float* side = reinterpret_cast<float*>(lds + OFF_SIDE);
+    for (int o = tid; o < 4 * D; o += 512) side[SIDE_WFT / 4 + o] = o < (a.p + 1) * D ? a.wft[o] : 0.f;
     if (tid < D) side[SIDE_B1 / 4 + tid] = a.b[0][tid];
     else if (tid < 2 * D) side[SIDE_B2 / 4 + tid - D] = a.b[1][tid - D];
   }
@@ -328,13 +327,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int s = (r >> 2) & 3;
   const unsigned fb = unsigned(r * ROWB + 8 * (g ^ s));                    // base of the forward A-fragments
   const unsigned sb = unsigned((16 * wave + r) * ROWB + 8 * (g ^ s));      // base of this lane's staging pieces
+  const float* const wft = reinterpret_cast<const float*>(lds + OFF_SIDE + SIDE_WFT);
   const float* const b1 = reinterpret_cast<const float*>(lds + OFF_SIDE + SIDE_B1);
   const float* const b2 = reinterpret_cast<const float*>(lds + OFF_SIDE + SIDE_B2);
   const unsigned uE = unsigned(a.E), uN = unsigned(a.N);
   float gmax = 0.f;
 
   // what a tile needs from the plan: node rows of the two endpoints and the edge row itself
-  struct Where { unsigned row, srow; bool live; unsigned idst; };
+  struct Where { unsigned row, srow; bool live; unsigned isrc, idst; };
   const float rcpE = 1.f / float(a.E);
   auto locate = [&](int tile) {
     Where wq;
@@ -347,19 +347,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int q = int(wq.row) - b * int(uE);
     if (q < 0) { q += int(uE); --b; }
     if (q >= int(uE)) { q -= int(uE); ++b; }
+    wq.isrc = unsigned(b) * uN + unsigned(a.src[q]);
     wq.idst = unsigned(b) * uN + unsigned(a.dst[q]);
     return wq;
   };
-  // a_0 of a tile comes back as the forward stored it (EdgeFwdResArgs::a0_out: the packed bf16 operand of Linear 1, 64 bytes per lane
-  // in four 16-byte loads): no endpoint gathers (16 load instructions and 1 KB per row in the first version), no input stage
-  auto load_a0 = [&](u32x4 (&dst)[4], unsigned row) {
-    const u32x4* ip = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.a0) + size_t(row) * (D * 2) + 16 * g);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c] = ip[4 * c];
-  };
+  f32x4 ps[NB], pd[NB];
+  float4 fib;
   Where cur = locate(int(blockIdx.x));
-  u32x4 a0n[4];
-  load_a0(a0n, cur.row);
+  load_rows<NB>(ps, a.Ps + size_t(cur.isrc) * D, g);
+  load_rows<NB>(pd, a.Pd + size_t(cur.idst) * D, g);
+  fib = *reinterpret_cast<const float4*>(a.fiber + size_t(cur.row) * 4);
   // g_0 of the PREVIOUS tile, packed: its eight stores are issued two at a time between the phases of the next tile.  Issued
   // right after dgrad 1 they (a) fill the CU's store path in one burst and (b) sit, in the in-order vmcnt queue, between the
   // endpoint rows requested a tile ahead and their first use, which then waits for the stores to be acknowledged
@@ -388,9 +385,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float rstd = a.rstd[cur.row];
     const bool more = it + 1 < my_tiles;
     const Where nxt = locate(more ? tile + int(gridDim.x) : tile);
-    u32x4 a0p[4], a1p[4], a2p[4];
+    // ---- a_0 = relu(Ps[src] + Pd[dst] + Wf . fiber)   (chain.hip: k_chain_fwd IN_EDGE, same operations in the same order)
+    f32x4 act[NB];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a0p[c] = a0n[c];
+    for (int t = 0; t < NB; ++t) act[t] = ps[t] + pd[t];
+    {
+      const float fv[4] = {fib.x, fib.y, fib.z, fib.w};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (c < a.p) axpy_features(act, wft + c * D, fv[c], g);
+      const float nrm = a.p == 1 ? fib.y : (a.p == 2 ? fib.z : fib.w);
+      axpy_features(act, wft + a.p * D, nrm, g);
+    }
+    u32x4 a0p[4], a1p[4], a2p[4];
+    relu_pack(a0p, act);
     EF_STAMP(1);
     if (it > 0) store_g0(0);
     f32x4 acc[NB];
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // two fused multiply-adds per element, g_3 = fma(-c1, y, fma(c0, dy, c2)) with c0 = rstd, c1 = rstd * mean(dy y),
     // c2 = -rstd * mean(dy): a quarter of the VALU work of the literal form (the chain waves are issue-bound: every VALU
     // operation delays the MFMAs behind it; the packed ReLU alone was worth 11 % of this kernel)
-    f32x4 gr[NB], act[NB];   // act: the messages y of this tile's rows as fp32
+    f32x4 gr[NB];
     {
       f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
@@ -426,8 +434,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int t = 0; t < NB; ++t) gr[t] = __builtin_elementwise_fma(v1, act[t], __builtin_elementwise_fma(v0, dy[t], v2));
     }
     if (it > 0) store_g0(6);
-    // ---- the next tile's a_0 is requested now: it lands under the three gradient stages
-    load_a0(a0n, nxt.row);
+    // ---- the next tile's endpoint rows are requested now: they land under the three gradient stages
+    load_rows<NB>(ps, a.Ps + size_t(nxt.isrc) * D, g);
+    load_rows<NB>(pd, a.Pd + size_t(nxt.idst) * D, g);
+    fib = *reinterpret_cast<const float4*>(a.fiber + size_t(nxt.row) * 4);
     u32x4 gb[4];
     pack(gb, gr);
     EF_STAMP(4);
@@ -569,7 +579,7 @@ bool edge_fused_supported(int64_t D_, int H, int64_t p, int precision) {
 size_t edge_fused_part_floats() { return size_t(kEdgeFusedMaxWg) * (DW_FLOATS + DB_FLOATS); }
 
 int launch_edge_fused_bwd(EdgeFusedBwdArgs a, int* nwg_out, hipStream_t s) {
-  BSMS_REQUIRE(a.R < (int64_t(1) << 31), BSMS_E_UNSUPPORTED, "edge_fused_bwd: R = %lld", (long long)a.R);
+  BSMS_REQUIRE(a.R < (int64_t(1) << 31) && a.p >= 1 && a.p <= 3, BSMS_E_UNSUPPORTED, "edge_fused_bwd: R = %lld, p = %d", (long long)a.R, a.p);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fused_bwd),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fused_bwd: cannot reserve %d bytes of LDS", LDS_BYTES);

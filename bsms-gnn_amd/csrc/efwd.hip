@@ -190,11 +190,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // ---- the three Linears, activations in registers between them
     u32x4 bb[4];
     relu_pack(bb, act);
-    if (a.a0_out && live) {   // a_0 as it enters Linear 1, kept for the fused backward (which then gathers nothing and repeats no input stage)
-      u32x4* op = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.a0_out) + row * (D * 2) + 16 * g);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) op[4 * c] = bb[c];
-    }
     stage(acc, bb, lds, bias, lane);
     relu_pack(bb, acc);
     stage(acc, bb, lds + W_BYTES, bias + D, lane);

@@ -59,7 +59,7 @@ void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, i
 // ================================================================================== GMP layout
 struct GmpSaved {
   float *e_act[kMaxStages], *e_y, *e_rstd, *aggr, *e_fiber;
-  float* e_a0;          // fused edge backward (efuse.hip): a_0 as bf16 in operand order, B * E * D / 2 floats
+  float *e_Ps, *e_Pd;   // fused edge backward (efuse.hip): the two node projections are kept for the backward's recompute
   float *n_act[kMaxStages], *n_yln, *n_rstd;
   // packs (fragment order)
   float *e_wi, *e_wj, *e_wft, *e_w[kMaxStages], *e_wt[kMaxStages], *e_wit, *e_wjt;
@@ -86,7 +86,7 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
   const size_t edge_act = bf ? pad_rows(re) * (size_t(D) / 2 + mask_words_per_row(D)) : act_floats(re, D);
   if (training && !fused)
     for (int l = 0; l < H; ++l) s.e_act[l] = c.take(edge_act);
-  if (training && fused) s.e_a0 = c.take(re * D / 2);
+  if (training && fused) { s.e_Ps = c.take(rn * D); s.e_Pd = c.take(rn * D); }
   s.e_y = c.take(bf ? re * D / 2 : re * D);
   if (training) s.e_rstd = c.take(re);
   if (training) s.e_fiber = c.take(re * 8);   // [B*E, fiber_ld(p)]: sized for the widest pitch (p is not part of the size query)
@@ -281,8 +281,8 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, bf, bfn);
   if (do_prepack && (rc = prepack_block(sv, D, p, H, training, params, s, bf, bfn))) return rc;
   const bool fused = training && use_edge_fused(D, H, precision);   // the backward recomputes the edge activations (efuse.hip)
-  float* const Ps = wk.Ps;
-  float* const Pd = wk.Pd;
+  float* const Ps = fused ? sv.e_Ps : wk.Ps;
+  float* const Pd = fused ? sv.e_Pd : wk.Pd;
 
   // node pre-projections
   {
@@ -295,13 +295,12 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   // edge MLP + LayerNorm
   // bf16 precisions at D = 128, hidden = 3: the kernel with LDS-resident weights (efwd.hip) -- whenever no edge activation has to
   // be saved, i.e. inference and the training forward of the fused backward (efuse.hip recomputes them)
-  if (edge_fwd_res_supported(D, H, p, precision) && (fused || (!training && g_edge_fwd_res))) {   // (the fused backward needs this kernel's a_0)
+  if (g_edge_fwd_res && edge_fwd_res_supported(D, H, p, precision) && (!training || fused)) {
     EdgeFwdResArgs a{};
     a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
     a.Ps = Ps; a.Pd = Pd; a.pos = pos; a.pos_bstride = pos_bstride; a.p = (int)p; a.wft = sv.e_wft;
     for (int l = 1; l <= 3; ++l) a.wp[l - 1] = reinterpret_cast<const float4*>(sv.e_w[l]);
     a.y = sv.e_y; a.rstd = training ? sv.e_rstd : nullptr; a.fiber_out = training ? sv.e_fiber : nullptr;
-    a.a0_out = training ? sv.e_a0 : nullptr;
     if ((rc = launch_edge_fwd_res(a, s))) return rc;
   } else {
     ChainFwdArgs a{};
@@ -423,8 +422,8 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   // edge MLP backward (gradient of the aggregation = gather by target)
   if (fused) {   // recompute + LayerNorm backward + dgrad + the weight gradients of Linears 1..H on chip (efuse.hip)
     EdgeFusedBwdArgs a{};
-    a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.dst = plan->dst;
-    a.a0 = sv.e_a0;
+    a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
+    a.Ps = sv.e_Ps; a.Pd = sv.e_Pd; a.fiber = sv.e_fiber; a.wft = sv.e_wft; a.p = (int)p;
     const float* const* pe = params + 2 * nl;
     for (int l = 1; l <= 3; ++l) { a.wr[l - 1] = reinterpret_cast<const float4*>(sv.e_wr[l]); a.b[l - 1] = pe[2 * l + 1]; }
     a.dy = wk.daggr; a.y = sv.e_y; a.rstd = sv.e_rstd; a.g0 = wk.gE[0];
