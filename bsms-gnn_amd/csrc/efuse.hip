@@ -347,6 +347,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int q = int(wq.row) - b * int(uE);
     if (q < 0) { q += int(uE); --b; }
     if (q >= int(uE)) { q -= int(uE); ++b; }
+    if (unsigned(q) >= uE) { b = int(wq.row / uE); q = int(wq.row - unsigned(b) * uE); }   // estimate off by more than one (tiny E, huge B): exact
     wq.isrc = unsigned(b) * uN + unsigned(a.src[q]);
     wq.idst = unsigned(b) * uN + unsigned(a.dst[q]);
     return wq;

@@ -105,6 +105,7 @@ __device__ __forceinline__ EdgeRef edge_ref(unsigned row, unsigned E, float rcpE
   int q = int(row) - b * int(E);
   if (q < 0) { q += int(E); --b; }
   if (q >= int(E)) { q -= int(E); ++b; }
+  if (unsigned(q) >= E) { b = int(row / E); q = int(row - unsigned(b) * E); }   // estimate off by more than one (tiny E, huge B): exact
   return EdgeRef{b, q};
 }
 
