@@ -142,6 +142,7 @@ struct ChainBwdArgs {
   int nload;          // loader waves per workgroup (the last `nload` waves of the block)
   int nring;          // depth of the LDS weight ring of this launch (3..6)
   float* gmax[kMaxStages + 1];   // like ChainFwdArgs::amax for gstore[k] (the gradient entering stage k; [nstage]: the last one). Nullable.
+  int ablate;         // experiment builds only (k_edge_bwd): every tile stores its layer gradients gstore[0..nstage-1] to tile 0 (no HBM stream)
 };
 
 // prepack table ---------------------------------------------------------------------------------

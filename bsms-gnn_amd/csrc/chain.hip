@@ -2201,7 +2201,12 @@ void k_edge_bwd(ChainBwdArgs a) {
 #pragma unroll
         for (int w = 0; w < W; ++w)
           mbits[rb][w] = reinterpret_cast<const unsigned*>(a.mask[k] + pad_rows(a.R) * D)[rowc[rb] * (4 * W) + lg * W + w];
-      stage_rb<NB, RB, true, false, true, 1, LONE>(acc, g, ring, slot, lane, pending + int64_t(tile) * (tile_rows * D), nullptr, off, moff, brow, k);
+#ifdef BSMS_EXPERIMENTS   // ablation bound of the fused dataflow (profiles/r05_fusion_bound.txt): the layer gradients of every tile land on tile 0
+      float* const gtile = pending + int64_t(a.ablate ? 0 : tile) * (tile_rows * D);
+#else
+      float* const gtile = pending + int64_t(tile) * (tile_rows * D);
+#endif
+      stage_rb<NB, RB, true, false, true, 1, LONE>(acc, g, ring, slot, lane, gtile, nullptr, off, moff, brow, k);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll

@@ -445,6 +445,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     }
     if (!bf) for (int k = 0; k <= (g_node_bf3 ? H - 1 : H); ++k) a.gmax[k] = sv.bound + size_t(16 + k) * kBoundWidth;   // gE[0] feeds only the projections' jobs
     else if (!g_node_bf3) a.gmax[H] = sv.bound + size_t(16 + H) * kBoundWidth;   // bf16 precision: only gE[0] (fp32 scatter sums dPs / dPd feed fp32 weight-gradient jobs)
+    a.ablate = (g_debug_flags & 2048) ? 1 : 0;   // experiments: bit 11 = no stream of gE[1..H] (with bits 0 and 10: the traffic a fused backward would not have)
     if ((rc = launch_chain_bwd((int)D, G_EDGE_LN, F_NONE, a, s))) return rc;
   }
   // From here two independent strands run CONCURRENTLY (fork/join on an internal side stream):
@@ -478,7 +479,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
       float* const dbs[3] = {ge[3], ge[5], ge[7]};
       if ((rc = launch_edge_fused_reduce(wk.ef_part, ef_nwg, dWs, dbs, ws))) return rc;
     }
-    for (int l = 1; l <= H && !fused; ++l) {   // edge Linears: bf16 gradient and activation tensors in the bf16 precision
+    for (int l = 1; l <= H && !fused && !(g_debug_flags & 1024); ++l) {   // edge Linears: bf16 gradient and activation tensors in the bf16 precision (experiments: bit 10 drops these jobs)
       add_job(wk.gE[l], sv.e_act[l - 1], ge[2 * l], ge[2 * l + 1], B * E, (int)D, 0, bd(16 + (H - l)), bd(l - 1));
       jobs[nj - 1].bf16 = bf;
     }
