@@ -243,6 +243,27 @@ struct EdgeFusedBwdArgs {
   int ntiles;                 // filled by the launcher
   unsigned long long* timing; // experiments only: phase stamps (null in production)
 };
+// efuse32.hip: the same in fp32 (BSMS_F32): weights streamed through the LDS ring in the order [W_1, W_2, W_3^T, W_2^T, W_1^T] per tile,
+// running block exponents for the dW operands; partials in the layout of efuse.hip (launch_edge_fused_reduce sums them)
+struct EdgeFused32Args {
+  int64_t R;                  // B * E edge rows (plan order)
+  int32_t E, N;
+  const int32_t *src, *dst;   // plan-order endpoints
+  const float *Ps, *Pd;       // the forward's node projections [B*N, D]
+  const float* fiber;         // [R, 4]
+  const float* wft;           // fiber weights^T [p+1][D]
+  int p;
+  const float4* wseq[5];      // packs in execution order: FRAG of Linears 1, 2; FRAG_T of Linears 3, 2, 1 (biases ride in the FRAG packs)
+  const float* dy;            // [B*N, D] gradient of the aggregate (gathered by target)
+  const float* y;             // [R, D] messages
+  const float* rstd;          // [R]
+  float* g0;                  // [pad_rows(R), D]: gradient w.r.t. the first edge Linear's output
+  float* part;                // per-workgroup partials, edge_fused_part_floats() floats
+  int ntiles;                 // filled by the launcher
+  unsigned long long* timing; // experiments only: phase stamps (null in production)
+};
+bool edge_fused32_supported(int64_t D, int H, int64_t p, int precision);
+int launch_edge_fused32_bwd(EdgeFused32Args a, int* nwg_out, hipStream_t s);
 constexpr int kEdgeFusedMaxWg = 256;
 bool edge_fused_supported(int64_t D, int H, int64_t p, int precision);
 size_t edge_fused_part_floats();

@@ -101,7 +101,8 @@ GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D,
   Carver& k = packs_base ? cp : c;
   s.e_wi = k.take(dd); s.e_wj = k.take(dd); s.e_wft = k.take(size_t(8) * D);
   if (training) { s.e_wit = k.take(dd); s.e_wjt = k.take(dd); }
-  for (int l = 1; l <= H; ++l) { s.e_w[l] = k.take(dd); if (training && !fused) s.e_wt[l] = k.take(dd); if (training && fused) s.e_wr[l] = k.take(size_t(D) * 72); }
+  // transposed packs: the unfused backward and the fp32 fused one (efuse32.hip streams them); row images: the bf16 fused one (efuse.hip)
+  for (int l = 1; l <= H; ++l) { s.e_w[l] = k.take(dd); if (training && (!fused || !bf)) s.e_wt[l] = k.take(dd); if (training && fused && bf) s.e_wr[l] = k.take(size_t(D) * 72); }
   s.n_w0x = k.take(dd); s.n_w0a = k.take(dd);
   if (training) { s.n_w0xt = k.take(dd); s.n_w0at = k.take(dd); }
   for (int l = 1; l <= H; ++l) { s.n_w[l] = k.take(dd); if (training) s.n_wt[l] = k.take(dd); }
@@ -162,7 +163,17 @@ static const int g_edge_fwd_res = env_fwd_res();   // A/B against the generic ri
 #else
 constexpr int g_edge_fwd_res = 1;
 #endif
-bool use_edge_fused(int64_t D, int H, int precision) { return g_edge_fused && edge_fused_supported(D, H, 1, precision); }
+// The fp32 port (efuse32.hip): under development -- experiment builds switch it on with BSMS_EDGE_FUSED_F32=1, the production build
+// keeps the unfused fp32 dataflow until the same-box A/B says otherwise (profiles/r05_efuse32_ab.txt).
+#ifdef BSMS_EXPERIMENTS
+static int env_fused32() { const char* e = getenv("BSMS_EDGE_FUSED_F32"); return e ? atoi(e) : 0; }
+static const int g_edge_fused32 = env_fused32();
+#else
+constexpr int g_edge_fused32 = 0;
+#endif
+bool use_edge_fused(int64_t D, int H, int precision) {
+  return precision == BSMS_F32 ? (g_edge_fused32 && edge_fused32_supported(D, H, 1, precision)) : (g_edge_fused && edge_fused_supported(D, H, 1, precision));
+}
 
 int check_gmp(const bsms_plan_t* plan, int64_t B, int64_t D, int64_t p, int H, const char* who) {
   BSMS_REQUIRE(plan != nullptr, BSMS_E_INVALID_ARG, "%s: plan is null", who);
@@ -420,7 +431,17 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     if ((rc = launch_chain_bwd((int)D, G_ROWS_LN, F_HEADS2, a, s))) return rc;
   }
   // edge MLP backward (gradient of the aggregation = gather by target)
-  if (fused) {   // recompute + LayerNorm backward + dgrad + the weight gradients of Linears 1..H on chip (efuse.hip)
+  if (fused && !bf) {   // the same in fp32 (efuse32.hip): packs streamed through the LDS ring, running block exponents for the dW operands
+    EdgeFused32Args a{};
+    a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
+    a.Ps = sv.e_Ps; a.Pd = sv.e_Pd; a.fiber = sv.e_fiber; a.wft = sv.e_wft; a.p = (int)p;
+    a.wseq[0] = reinterpret_cast<const float4*>(sv.e_w[1]); a.wseq[1] = reinterpret_cast<const float4*>(sv.e_w[2]);
+    for (int l = 3; l >= 1; --l) a.wseq[2 + (3 - l)] = reinterpret_cast<const float4*>(sv.e_wt[l]);
+    a.dy = wk.daggr; a.y = sv.e_y; a.rstd = sv.e_rstd; a.g0 = wk.gE[0];
+    a.part = wk.ef_part;
+    a.timing = g_timing;
+    if ((rc = launch_edge_fused32_bwd(a, &ef_nwg, s))) return rc;
+  } else if (fused) {   // recompute + LayerNorm backward + dgrad + the weight gradients of Linears 1..H on chip (efuse.hip)
     EdgeFusedBwdArgs a{};
     a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
     a.Ps = sv.e_Ps; a.Pd = sv.e_Pd; a.fiber = sv.e_fiber; a.wft = sv.e_wft; a.p = (int)p;

@@ -6,8 +6,8 @@ cd "$(dirname "$0")/../bsms-gnn_amd"
 name=$1; src=$2; flags=$3
 mkdir -p _build_exp
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBSMS_EXPERIMENTS"
-for s in plan rowsum chain efuse efwd wgrad gmp bsgmp optim hierarchy sim; do
-  if [ ! -f _build_exp/$s.o ] || [ csrc/$s.hip -nt _build_exp/$s.o ] || [ csrc/chain.h -nt _build_exp/$s.o ]; then
+for s in plan rowsum chain efuse efuse32 efwd wgrad gmp bsgmp optim hierarchy sim; do
+  if [ ! -f _build_exp/$s.o ] || [ csrc/$s.hip -nt _build_exp/$s.o ] || [ csrc/chain.h -nt _build_exp/$s.o ] || [ csrc/chain_dev.h -nt _build_exp/$s.o ]; then
     extra=""; { [ $s = rowsum ] || [ $s = sim ]; } && extra="-ffp-contract=off"
     /opt/rocm/bin/hipcc $F $extra -c csrc/$s.hip -o _build_exp/$s.o &
   fi
@@ -16,7 +16,7 @@ wait
 b=${src%.hip}
 /opt/rocm/bin/hipcc $F $flags -c csrc/$src -o _build_exp/${b}_$name.o
 objs=""
-for s in plan rowsum chain efuse efwd wgrad gmp bsgmp optim hierarchy sim; do
+for s in plan rowsum chain efuse efuse32 efwd wgrad gmp bsgmp optim hierarchy sim; do
   if [ $s = $b ]; then objs="$objs _build_exp/${b}_$name.o"; else objs="$objs _build_exp/$s.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib_$name.so.keep $objs
