@@ -189,7 +189,9 @@ __device__ __forceinline__ void gradient_wave(const EdgeFused32Args& a, char* ld
     for (int b4 = 0; b4 < 4; ++b4) {
       // piece_off(row, lane >> 1) with row = 16 LI + 4 b4 + rr: the swizzle term is b4 for the four rows -- one lane-dependent base per
       // batch and immediate row offsets (sixteen per-row addresses kept across the tile loop cost sixteen registers)
-      const unsigned base = 8u * (unsigned(lane >> 1) ^ unsigned(b4)) + 4u * unsigned(lane & 1);
+      unsigned ln = unsigned(lane);
+      asm volatile("" : "+v"(ln));   // opaque: keeps the four bases from being hoisted out of the tile loop (four registers the accumulators need)
+      const unsigned base = 8u * ((ln >> 1) ^ unsigned(b4)) + 4u * (ln & 1u);
       unsigned hw[4], lw[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
