@@ -175,10 +175,14 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
       pstride_l[i + 1] = pos_batch_stride ? s.N[i + 1] * p : 0;
     }
     if (!packs_ok) {
+      // two marks on the lane: the packs of the down path + bottom block (slot 0: waited for behind block 0) and those of the up path
+      // (slot 1: waited for in front of the first up block).  One join behind block 0 made the caller's stream wait for all 2L
+      // prepacks -- 130-160 us per step at D = 256, where a block's prepack takes 55 us (profiles/r05_surface_join_ab.txt)
       if ((rc = side_lane(&lane0, 0)) || (rc = side_fork(lane0, st))) return rc;
       for (int k = 1; k <= 2 * L; ++k) {
         const int lv = level_of_block(k, L);
         if ((rc = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream, precision))) return rc;
+        if ((k == L || k == 2 * L) && (rc = side_mark(lane0, k == L ? 0 : 1))) return rc;
       }
     }
   }
@@ -186,7 +190,7 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
   for (int i = 0; i < L; ++i) {
     if ((rc = gmp_fwd_core(plans[i], hi, pos_l[i], B, D, p, pstride_l[i], hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp,
                            packs_of(i), i == 0 && !packs_ok, nullptr, st, precision))) return rc;
-    if (i == 0 && ((lane && (rc = side_join(lane, st))) || (lane0 && (rc = side_join(lane0, st))))) return rc;
+    if (i == 0 && ((lane && (rc = side_join(lane, st))) || (lane0 && (rc = side_wait_mark(lane0, 0, st))))) return rc;
     // restrict the features to the kept nodes (ops/BSMS.py:74, 79-83)
     if ((rc = bsms_edge_conv(plans[i], w.skip[i], B, D, ew[i], 1, 1, v.hin[i + 1], stream))) return rc;
     hi = v.hin[i + 1];
@@ -196,6 +200,7 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
   float* cur = (L == 0) ? out : w.a[0];
   if ((rc = gmp_fwd_core(plans[L], hi, pi, B, D, p, pstride, hidden, block(params, L, hidden), cur, v.gmp[L], w.gmp, packs_of(L),
                          L == 0 && !packs_ok, nullptr, st, precision))) return rc;
+  if (lane0 && (rc = side_wait_mark(lane0, 1, st))) return rc;   // the up blocks' packs
   for (int i = 0; i < L; ++i) {
     const int d = L - 1 - i;
     if ((rc = bsms_edge_conv(plans[d], cur, B, D, ew[d], 0, 1, v.upin[d], stream))) return rc;   // prolong (BSMS.py:98-100)
