@@ -65,10 +65,16 @@ Saved carve_saved(void* base, const Shape& s, bool training) {
   return v;
 }
 
+constexpr size_t kPerBlockScratchCap = size_t(8) << 30;   // the size query serves training and inference alike: bounds what a forward-only caller carries unused
+// level of the block that runs k-th in the BACKWARD: up blocks on levels 0 .. L-1, the bottom block, down blocks on levels L-1 .. 0
+inline int level_of_block_bwd(int k, int L) { return k < L ? k : (k == L ? L : 2 * L - k); }
+
 struct Work {
   void* gmp;                      // scratch of one block call (largest level)
   void* gmp_b;                    // second scratch set: the backward alternates so that block k's weight gradients (side
                                   // lanes) can still be reading set k & 1 while block k+1 runs in the other
+  void* gmp_blk[2 * kMaxLevels + 1];  // OR one scratch set per block of the backward (in execution order; null when the sets together
+                                  // would exceed kPerBlockScratchCap): no block then waits for the lanes of the block before last
   float* skip[kMaxLevels];        // fwd: outputs of the down blocks; bwd: gradient arriving at the skip connections
   float* a[2];                    // two ping-pong level-0 sized buffers
   void* packs[2 * kMaxLevels + 1];  // inference: weight packs of every block (training keeps them in the saved blobs)
@@ -81,6 +87,20 @@ Work carve_work(void* base, const Shape& s) {
   for (int i = 0; i <= s.L; ++i) g = std::max(g, bsms_gmp_work_bytes(s.B, s.N[i], s.E[i], s.D, s.H));
   w.gmp = c.bytes(g);
   w.gmp_b = c.bytes(s.L > 0 ? g : 0);
+  // Per-block sets for the backward (round 5): 2L + 1 scratch sets sized for their own level -- 4.7 GB instead of 1.4 GB at the
+  // airfoil batch-8 shape, out of 288 GB; larger shapes than the cap keep the two alternating sets -- remove the 2L - 1 barrier packets with which block k waited for the side lanes of block
+  // k - 2 before reusing its set (each ~5 us of idle caller's stream; profiles/r05_perblock_scratch_ab.txt).  The first two blocks
+  // use gmp / gmp_b.
+  size_t extra = 0;
+  for (int k = 2; k <= 2 * s.L; ++k) {
+    const int lv = level_of_block_bwd(k, s.L);
+    extra += align_up(bsms_gmp_work_bytes(s.B, s.N[lv], s.E[lv], s.D, s.H));
+  }
+  const bool per_block = s.L > 0 && extra <= kPerBlockScratchCap;
+  for (int k = 0; k <= 2 * s.L; ++k) {
+    const int lv = level_of_block_bwd(k, s.L);
+    w.gmp_blk[k] = !per_block ? nullptr : (k == 0 ? w.gmp : (k == 1 ? w.gmp_b : c.bytes(bsms_gmp_work_bytes(s.B, s.N[lv], s.E[lv], s.D, s.H))));
+  }
   for (int i = 0; i < s.L; ++i) w.skip[i] = c.floats(size_t(s.B) * s.N[i] * s.D);
   for (int k = 0; k < 2; ++k) w.a[k] = c.floats(size_t(s.B) * s.N[0] * s.D);
   for (int k = 0; k <= 2 * s.L; ++k) w.packs[k] = c.bytes(gmp_pack_bytes(s.D, s.H));
@@ -281,12 +301,13 @@ extern "C" int bsms_bsgmp_bwd_ev(const bsms_plan_t* const* plans, const float* c
   auto run_block = [&](int level, const float* x, const float* g_in, int k, float* gx) -> int {
     const int slot = nblk & 1;
     int r;
-    if (marked[slot] && ((!gmp_marks_chained() && (r = side_wait_mark(lane0, slot, st))) || (r = side_wait_mark(lane1, slot, st)))) return r;
+    void* const own = w.gmp_blk[nblk];   // this block's own scratch set, or null: alternate between the two shared ones
+    if (!own && marked[slot] && ((!gmp_marks_chained() && (r = side_wait_mark(lane0, slot, st))) || (r = side_wait_mark(lane1, slot, st)))) return r;
     const int order = nblk;   // position of this block in the backward's execution order
     ++nblk;
     marked[slot] = true;
     if ((r = gmp_bwd_core(plans[level], x, pos_l[level], g_in, B, D, p, pstride_l[level], hidden, block(params, k, hidden), v.gmp[k],
-                          slot ? w.gmp_b : w.gmp, gx, block(grads, k, hidden), slot, st, precision))) return r;
+                          own ? own : (slot ? w.gmp_b : w.gmp), gx, block(grads, k, hidden), slot, st, precision))) return r;
     // Gradient-bucket hand-off (bsms_bsgmp_bwd_ev): lane 1's mark of this block covers lane 0's (gmp_marks_chained) and both
     // lanes are in-order streams, so an event recorded on lane 1 HERE completes when every weight gradient of this block,
     // of the blocks before it and of anything queued on the lanes earlier (a deferred bsms_mlp_bwd_ex) has been written.
