@@ -107,6 +107,9 @@ __device__ __forceinline__ void gradient_wave(const EdgeFused32Args& a, char* ld
   constexpr int MINE = (R8::PER - LI + 3) / 4;
   const int gi = LI >> 1, gj = LI & 1;
   const int r = lane & 15, g = lane >> 4;
+#ifdef EFV_PRIO
+  __builtin_amdgcn_s_setprio(EFV_PRIO);   // experiments: the loaders / gradient waves ahead of the chain wave of their SIMD
+#endif
   const unsigned tb = unsigned((4 * g + (r >> 2)) * ROWB + 8 * ((r & 3) ^ g));   // supplier base of the transposing reads
   const char* const GH = lds + OFF_GH; const char* const GL = lds + OFF_GL;
   const char* const AH = lds + OFF_AH; const char* const AL = lds + OFF_AL;

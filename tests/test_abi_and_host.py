@@ -59,6 +59,20 @@ def test_size_queries_and_validation_without_gpu(eng):
     assert L.bsms_plan_destroy(None) == 0 and L.bsms_plan_num_nodes(None) == -1
 
 
+def test_build_lists_cover_the_source_tree():
+    """Every .hip of csrc/ is compiled and every header is part of the build digest (a header missing from the digest means a
+    stale library after an edit: chain_dev.h was added in round 5)."""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bsms-gnn_amd")
+    spec = importlib.util.spec_from_file_location("_bsms_build", os.path.join(here, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    on_disk = sorted(f for f in os.listdir(os.path.join(here, "csrc")) if f.endswith(".hip"))
+    assert sorted(b.SOURCES) == on_disk
+    headers = sorted(f for f in os.listdir(os.path.join(here, "csrc")) if f.endswith(".h"))
+    assert set(headers) <= {os.path.basename(h) for h in b.HEADERS}
+
+
 def test_precision_levels_match_the_header(eng):
     """`bsms_precision` (include/bsms_hip.h) and the Python names of the drop-in modules agree."""
     import os, re
