@@ -108,7 +108,9 @@ struct bsms_plan {
   float *k_w = nullptr, *p_w = nullptr;
   int64_t Ek = 0, Ep = 0;
   const float* w_bound = nullptr;
-  std::vector<int32_t> host;                         // host copy of the index block (set_pool derives the compact lists from it)
+  std::vector<int32_t> host;                         // host copy of the index block (set_pool derives the compact lists from it); released by the first
+                                                     // bsms_plan_set_pool -- a later re-pool reads the block back from the device (host_words int32)
+  size_t host_words = 0;
   int32_t *block = nullptr, *pool_block = nullptr;   // the two device allocations the pointers above point into
   size_t block_cap = 0, pool_cap = 0;                // their capacities in bytes (plan.hip recycles them)
   int device = 0;                                    // the device the blocks live on (current device at bsms_plan_create)

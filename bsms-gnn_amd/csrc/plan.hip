@@ -247,7 +247,8 @@ extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_p
     bsms_plan_destroy(p);
     return rc;
   }
-  p->host.swap(blk);   // kept: bsms_plan_set_pool builds the compact transition lists from it
+  p->host.swap(blk);   // kept until the first bsms_plan_set_pool, which builds the compact transition lists from it
+  p->host_words = p->host.size();
   p->rowptr = p->block;
   p->t_rowptr = p->rowptr + nN;
   p->src = p->t_rowptr + nN;
@@ -276,7 +277,21 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
   }
   // compact lists of the two pooled transitions (common.h), from the host copy of the CSR
   const size_t nN = idx_pad(size_t(p->N) + 1), nE = idx_pad(size_t(p->E));
-  const int32_t *rowptr = p->host.data(), *t_rowptr = rowptr + nN, *src = t_rowptr + nN, *perm = src + 2 * nE,
+  // the host copy of the CSR: kept since bsms_plan_create for the FIRST pooling only (a cache of 1024 plans used to carry ~2 MB each for
+  // good: ADVICE round 4); a plan that is pooled again reads its index block back from the device
+  std::vector<int32_t> readback;
+  if (p->host.empty()) {
+    BSMS_REQUIRE(p->block != nullptr && p->host_words > 0, BSMS_E_INVALID_ARG, "plan_set_pool: plan has no index block");
+    readback.resize(p->host_words);
+    int dev = 0;
+    BSMS_HIP_CHECK(hipGetDevice(&dev));
+    if (dev != p->device) BSMS_HIP_CHECK(hipSetDevice(p->device));
+    const hipError_t e = hipMemcpy(readback.data(), p->block, p->host_words * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (dev != p->device) (void)hipSetDevice(dev);
+    BSMS_REQUIRE(e == hipSuccess, BSMS_E_HIP, "plan_set_pool: reading the index block back: %s", hipGetErrorString(e));
+  }
+  const int32_t* const hostp = p->host.empty() ? readback.data() : p->host.data();
+  const int32_t *rowptr = hostp, *t_rowptr = rowptr + nN, *src = t_rowptr + nN, *perm = src + 2 * nE,
                 *t_dst = perm + nE, *t_eid = t_dst + nE;
   int64_t Ek = 0, Ep = 0;
   for (int64_t k = 0; k < Nk; ++k) Ek += rowptr[h_ids[k] + 1] - rowptr[h_ids[k]];
@@ -322,6 +337,10 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
   p->Nk = Nk;
   p->Ek = Ek;
   p->Ep = Ep;
+  if (!p->host.empty()) {   // the compact lists are built: the host copy has served its purpose
+    p->host_words = p->host.size();
+    std::vector<int32_t>().swap(p->host);
+  }
   return BSMS_OK;
 }
 
