@@ -233,13 +233,12 @@ __device__ __forceinline__ void gradient_wave(const EdgeFused32Args& a, char* ld
   using U0 = std::integral_constant<int, 0>; using U4 = std::integral_constant<int, 4>; using U6 = std::integral_constant<int, 6>;
   using U8 = std::integral_constant<int, 8>; using U12 = std::integral_constant<int, 12>; using U16 = std::integral_constant<int, 16>;
   for (int it = 0; it < my_tiles; ++it) {
-    chunk_step(); dw_units(L0{}, U0{}, U4{});            // 0: pair 1 of the PREVIOUS tile (staged after its last stage): five quiet periods
-    chunk_step(); dw_units(L0{}, U4{}, U8{});            // 1
-    chunk_step(); dw_units(L0{}, U8{}, U12{});           // 2
-    chunk_step(); dw_units(L0{}, U12{}, U16{});          // 3
-    chunk_step(); bias_sums(L0{});                       // 4
-    chunk_step(); chunk_step(); chunk_step();            // 5-7
-    chunk_step(); update_exps(L2{});                     // 8: maxima of (g_3, a_2), published before this barrier
+    chunk_step(); chunk_step(); chunk_step(); chunk_step();   // 0-3: loading only (the first forward stage runs at the ring's pace)
+    chunk_step(); dw_units(L0{}, U0{}, U4{});            // 4: pair 1 of the PREVIOUS tile (staged after its last stage) in the periods that
+    chunk_step(); dw_units(L0{}, U4{}, U8{});            // 5  have no pair of their own; the staging tile is rewritten behind barrier 11
+    chunk_step(); dw_units(L0{}, U8{}, U12{});           // 6
+    chunk_step(); dw_units(L0{}, U12{}, U16{});          // 7
+    chunk_step(); update_exps(L2{}); bias_sums(L0{});    // 8: maxima of (g_3, a_2), published before this barrier
     chunk_step(); chunk_step(); chunk_step();            // 9-11
     chunk_step(); update_exps(L1{}); dw_units(L2{}, U0{}, U6{});    // 12: pair 3 was staged between barriers 11 and 12
     chunk_step(); dw_units(L2{}, U6{}, U12{});           // 13
@@ -350,9 +349,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   load_rows<NB>(ps, a.Ps + cur.isrc * D, g);
   load_rows<NB>(pd, a.Pd + cur.idst * D, g);
   fib = *reinterpret_cast<const float4*>(a.fiber + size_t(cur.row) * 4);
+  // g_0 of the PREVIOUS tile: its eight stores go out in three batches between the first phases of the next tile -- issued in one
+  // burst behind the last stage the four chain waves fill the CU's store path (~10 B/clk) and sit on it for 2.5k cycles (timeline)
+  f32x4 g0v[NB];
+  int64_t g0off = -1;
+  auto store_g0 = [&](int t0, int t1) {
+    if (g0off < 0) return;   // per lane: rows past the end (and the first tile) store nothing
+    float* rowp = a.g0 + g0off;
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+      if (t >= t0 && t < t1) *reinterpret_cast<f32x4*>(rowp + 16 * t + 4 * g) = g0v[t];
+  };
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = int(blockIdx.x) + it * int(gridDim.x);
     EF32_STAMP(0);
+    store_g0(0, 3);
     const int64_t row64 = cur.row64;
     const bool live = cur.live;
     const unsigned row = cur.row;
@@ -372,9 +383,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       relu_into<NB>(a0, acc);
     }
     const float m0 = row_amax<NB>(a0);
+    store_g0(3, 6);
     EF32_STAMP(1);
     mfma_stage<NB, true, 2>(acc, a0, scale_of(m0), ring, slot, lane);
     relu_into<NB>(a1, acc);
+    store_g0(6, 8);
     EF32_STAMP(2);
     const float m1a = row_amax<NB>(a1);
     f32x4 gr[NB], yr[NB];   // requested now, used after the second Linear
@@ -440,10 +453,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     hand_over(0, gr, a0);
     EF32_STAMP(11);
     // ---- g_0: input of the scatter / fiber-gradient kernel (plain stores: read next, they stay in L2 / the memory-side cache)
-    store_rows<NB, false>(gn, a.g0, live ? int64_t(row64) * D : -1, g);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) g0v[t] = gn[t];
+    g0off = live ? int64_t(row64) * D : -1;
     EF32_STAMP(12);
     cur = nxt;
   }
+  store_g0(0, 8);   // the last tile's
   lds_barrier();   // the last pair is staged: the gradient waves finish behind this barrier
 }
 
