@@ -25,6 +25,53 @@ namespace bsms {
 static std::mutex g_lane_mu;
 static SideLane g_lanes[64][kSideLanes];
 
+// Can work queued on `b` overtake work queued on `a`?  HIP maps its streams onto a few hardware queues (4 by default), by the
+// reference counts at creation time; two streams on ONE queue run in order.  Found in round 5: in a process that had built eight
+// meshes' plans first (their upload stream, torch's copy-stream pool) both side lanes landed on one hardware queue and the
+// block-diagonal cylinder step ran 6-20 % slower than in a process where the lanes happened to be created earlier
+// (profiles/r05_hw_queues.txt).  The probe: ~250 us of fills on `a`, one small fill + event on `b`; if that event completes while
+// `a` is still busy the queues are distinct.  Runtime API only (this file is also built as plain C++ for the sanitizer tests).
+static bool can_overtake(hipStream_t a, hipStream_t b) {
+  constexpr size_t kBytes = size_t(64) << 20;
+  char* buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), kBytes + 256) != hipSuccess) { (void)hipGetLastError(); return true; }   // cannot tell
+  hipEvent_t ea = nullptr, eb = nullptr;
+  bool distinct = true;
+  if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess) {
+    bool ok = true;
+    for (int i = 0; i < 16 && ok; ++i) ok = hipMemsetAsync(buf, 0, kBytes, a) == hipSuccess;
+    ok = ok && hipEventRecord(ea, a) == hipSuccess && hipMemsetAsync(buf + kBytes, 0, 256, b) == hipSuccess && hipEventRecord(eb, b) == hipSuccess &&
+         hipEventSynchronize(eb) == hipSuccess;
+    if (ok) distinct = hipEventQuery(ea) == hipErrorNotReady;
+    (void)hipEventSynchronize(ea);
+    (void)hipGetLastError();
+  }
+  if (ea) (void)hipEventDestroy(ea);
+  if (eb) (void)hipEventDestroy(eb);
+  (void)hipFree(buf);
+  return distinct;
+}
+
+// a non-blocking stream that shares its hardware queue neither with the legacy default stream (what PyTorch runs on) nor with the
+// lanes that exist already; streams that failed the probe are kept until one passes (each raises the reference count of the queue
+// it sits on, so the next creation goes elsewhere), then destroyed
+static int create_lane_stream(hipStream_t* out, const SideLane* lanes, int which) {
+  std::vector<hipStream_t> ballast;
+  hipStream_t st = nullptr;
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    BSMS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));   // (a lower or higher stream priority for the lanes: +-0, profiles/README.md)
+    bool good = can_overtake(nullptr, st);
+    for (int k = 0; k < kSideLanes && good; ++k)
+      if (k != which && lanes[k].stream) good = can_overtake(lanes[k].stream, st);
+    if (good || attempt == 5) break;   // after six tries: keep the last one (four hardware queues cannot separate every stream of a process)
+    ballast.push_back(st);
+    st = nullptr;
+  }
+  for (hipStream_t b : ballast) (void)hipStreamDestroy(b);
+  *out = st;
+  return BSMS_OK;
+}
+
 int side_lane(SideLane** out, int which) {
   int dev = 0;
   BSMS_HIP_CHECK(hipGetDevice(&dev));
@@ -39,7 +86,7 @@ int side_lane(SideLane** out, int which) {
       BSMS_HIP_CHECK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, atoi(e) < 0 ? least : greatest));
     } else
 #endif
-    BSMS_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));   // (a lower or higher stream priority for the lanes: +-0, profiles/README.md)
+    { int rc_ = create_lane_stream(&l.stream, g_lanes[dev], which); if (rc_) return rc_; }
     // same-device stream ordering only: no timing, and no system-scope fence when an event completes (the kernels'
     // own end-of-kernel release / start-of-kernel acquire make their data visible device-wide; the extra fence is for
     // hosts and other devices reading behind the event, which nothing here does)
