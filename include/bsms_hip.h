@@ -18,6 +18,10 @@
  *     per device, two lazily created internal side streams (+ two events each) that bsms_gmp_bwd uses to
  *     overlap its weight-gradient kernels with its gradient scatters (forked from and joined back into
  *     `stream` inside the call, also legal under HIP-graph capture).
+ *     The FIRST call that needs a side stream creates it and checks once, with a few device fills on a temporary
+ *     64 MB allocation (~1 ms, outside any graph capture), that it does not share its hardware queue with the default
+ *     stream or the other side stream -- HIP places streams on four hardware queues and two streams on one queue
+ *     run in order.
  *   - Arithmetic: fp32 in, fp32 out, fp32 accumulation.  Matrix products run on the f16 matrix cores as three
  *     partial products of two-way fp16 splits (11 + 11 significand bits) of power-of-two-scaled fp32 operands.
  *     Forward and input-gradient products scale per activation ROW and per weight MATRIX: the result is at least as
