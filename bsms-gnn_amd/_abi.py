@@ -64,6 +64,7 @@ SIGNATURES = {
     "bsms_bsgmp_bwd_ev": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p,
                                   c_void_p, c_void_p, PP, c_int, c_int, PP, c_void_p]),
     "bsms_side_lanes_join": (c_int, [c_void_p]),
+    "bsms_streams_overlap": (c_int, [c_void_p, c_void_p]),
     "bsms_sim_work_bytes": (c_size_t, [c_i64]),
     "bsms_sim_prologue": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bsms_sim_epilogue": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p,

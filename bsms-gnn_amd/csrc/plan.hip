@@ -138,6 +138,17 @@ int side_wait_mark(SideLane* lane, int slot, hipStream_t main) {
 
 using namespace bsms;
 
+// 1: work queued on `b` can overtake work queued on `a` (the two streams sit on different hardware queues); 0: they run in order.
+extern "C" int bsms_streams_overlap(bsms_stream_t a, bsms_stream_t b) {
+  hipStream_t sa = as_stream(a), sb = as_stream(b);
+  if (sa == sb) return 0;
+  hipStreamCaptureStatus ca = hipStreamCaptureStatusNone, cb = hipStreamCaptureStatusNone;
+  BSMS_REQUIRE(hipStreamIsCapturing(sa, &ca) == hipSuccess && hipStreamIsCapturing(sb, &cb) == hipSuccess &&
+               ca == hipStreamCaptureStatusNone && cb == hipStreamCaptureStatusNone, BSMS_E_UNSUPPORTED,
+               "streams_overlap: a stream is capturing (the probe allocates and synchronises)");
+  return can_overtake(sa, sb) ? 1 : 0;
+}
+
 extern "C" int bsms_abi_version(void) { return 3; }  // 2: saved == NULL selects inference in *_fwd; 3: bsms_mlp_fwd_ex, larger saved buffers (bound slots)
 extern "C" const char* bsms_last_error(void) { return bsms::g_err; }
 

@@ -261,10 +261,21 @@ def _upload(t, device):
         # switching each (three per step = the whole difference between a host-fed and a device-resident step), while
         # the host runs a step ahead of the GPU, so on its own stream the copy has long finished when the step starts
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        cur = torch.cuda.current_stream(idx)
         cs = _COPY_STREAMS.get(idx)
         if cs is None:
-            cs = _COPY_STREAMS[idx] = torch.cuda.Stream(idx)
-        cur = torch.cuda.current_stream(idx)
+            # a stream that really runs beside the compute stream: HIP maps streams onto four hardware queues and two streams on
+            # one queue run in order -- take the first of torch's pool streams that the probe says can overtake `cur`
+            tried = []
+            for _ in range(6):
+                cs = torch.cuda.Stream(idx)
+                tried.append(cs)
+                try:
+                    if os.environ.get("BSMS_COPY_STREAM_PROBE", "1") == "0" or _abi.lib().bsms_streams_overlap(cur.cuda_stream, cs.cuda_stream) == 1:
+                        break
+                except Exception:      # noqa: BLE001  (no library / no GPU: any stream will do)
+                    break
+            _COPY_STREAMS[idx] = cs
         src = t if t.is_pinned() else t.pin_memory()
         with torch.cuda.stream(cs):
             out = src.to(torch.device("cuda", idx), non_blocking=True)

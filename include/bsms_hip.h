@@ -256,6 +256,13 @@ int bsms_bsgmp_bwd_ev(const bsms_plan_t* const* plans, const float* const* ew, i
                       const float* const* params, const void* saved, void* work, float* grad_h, float* const* grads,
                       int precision, int flags, void* const* block_done_events, bsms_stream_t stream);
 int bsms_side_lanes_join(bsms_stream_t stream);
+/* Do two streams overlap?  HIP places its streams on a few hardware queues (four by default, by reference counts at creation time) and
+ * two streams on one queue run in order, whatever their flags.  Returns 1 if work queued on `b` can overtake work queued on `a`, 0 if not
+ * (or a == b), < 0 on error.  Probes with ~250 us of device fills on `a` and a small one on `b` over a temporary 64 MB allocation:
+ * synchronises, not for the data path or graph capture.  The engine uses it for its own side streams; the host loader uses it to pick a
+ * copy stream that really runs beside the compute stream (graph.py: _to_device_async; no counterpart in the reference, whose loader
+ * copies on the compute stream, src/datasets/base.py via trainer/trainer.py:52-56). */
+int bsms_streams_overlap(bsms_stream_t a, bsms_stream_t b);
 /* bsms_mlp_bwd with `flags`.  BSMS_BWD_DEFER_JOIN: `grad_x` is complete in stream order when the call returns, the weight
  * gradients run on an internal side stream; same contract as above (`work`, `grads`, bsms_side_lanes_join). */
 int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, int64_t in_dim, int64_t D, int64_t out_dim, int H,

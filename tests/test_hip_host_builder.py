@@ -63,3 +63,20 @@ def test_bench_hierarchy_reaches_hbm_bit_exact(eng):
         assert np.array_equal(t_rowptr, np.concatenate([[0], np.cumsum(np.bincount(e[0], minlength=n))]).astype(np.int32))
         if l < len(m_ids):
             n = len(m_ids[l])
+
+
+@pytest.mark.gpu
+def test_streams_overlap_probe_and_side_lanes():
+    """bsms_streams_overlap: a stream never overtakes itself; among the first streams of a fresh pool at least one overlaps the
+    current stream (four hardware queues); the engine's two side lanes, created by the first backward, overlap each other -- the
+    property the probe exists for (in a process that built variable-mesh plans first they shared a queue)."""
+    import torch
+    import bsms_gnn_amd as eng
+    L = eng._abi.lib()
+    cur = torch.cuda.current_stream()
+    assert L.bsms_streams_overlap(cur.cuda_stream, cur.cuda_stream) == 0
+    pool = [torch.cuda.Stream() for _ in range(6)]
+    flags = [L.bsms_streams_overlap(cur.cuda_stream, s.cuda_stream) for s in pool]
+    assert all(f in (0, 1) for f in flags) and any(f == 1 for f in flags), flags
+    # two streams on which NOTHING distinguishes the queues must at least give a stable answer
+    assert L.bsms_streams_overlap(cur.cuda_stream, pool[flags.index(1)].cuda_stream) == 1
