@@ -169,7 +169,7 @@ def cpu_model():
     return "unknown"
 
 
-def _oracle_steps(kind, batch, threads, max_steps, budget_s):
+def _oracle_steps(kind, batch, threads, max_steps, budget_s, warm=1):
     """fwd + loss + bwd of the CPU oracle; returns (seconds per step: best after the warm-up step, steps run, loss)."""
     from oracle import bsms_oracle as ro
     torch.set_num_threads(threads)
@@ -185,11 +185,11 @@ def _oracle_steps(kind, batch, threads, max_steps, budget_s):
         loss = ro.masked_rmse(sim(data, True, False), wl["target"], wl["mask"])
         loss.backward()
         times.append(time.perf_counter() - t0)
-    best = min(times[1:]) if len(times) > 1 else times[0]   # the first step doubles as warm-up when there is time
+    best = min(times[warm:]) if len(times) > warm else min(times[1:]) if len(times) > 1 else times[0]   # the first step(s) double as warm-up when there is time
     return best, len(times), float(loss.detach())
 
 
-def cpu_baseline(kind, batch, budget_s=30.0):
+def cpu_baseline(kind, batch, budget_s=30.0, steps=0):
     """The oracle (CPU restatement of the reference path, `kind: port`) on the host cores, bounded to about
     `budget_s` + 15 s of CPU work so that the default bench run stays within minutes (SURVEY.md section 8d asks for
     best-of-5: at 5-15 s per airfoil step that is minutes, so the sample is 1 warm-up + up to 3 timed steps):
@@ -198,6 +198,16 @@ def cpu_baseline(kind, batch, budget_s=30.0):
       * 1 thread: the SAME batch-`batch` step on one thread (one warm-up step when it fits the budget, then one timed
         step: ~11 s each at airfoil size) -- measured, not scaled from a smaller batch."""
     threads = max(1, min(usable_cpus(), 32))
+    if steps > 0:   # --cpu-baseline-steps K: SURVEY.md 8(d)'s protocol -- 2 warm-ups + best of K, however long it takes
+        best, n, loss = _oracle_steps(kind, batch, threads, 2 + steps, 1e9, warm=2)
+        one, n1, _ = _oracle_steps(kind, batch, 1, 2, 0.6 * budget_s)
+        torch.set_num_threads(threads)
+        return {"value": 1.0 / best, "unit": "steps/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+                "sample": f"{kind}-like B={batch} fwd+loss+bwd, 2 warm-up steps + best of {steps} (SURVEY.md 8(d) protocol), fp32, "
+                          f"torch CPU {torch.__version__}, {threads} threads of {os.cpu_count()} logical CPUs",
+                "ms_per_step": best * 1e3, "loss": loss,
+                "one_thread": {"value": 1.0 / one, "unit": "steps/s", "cores": 1, "ms_per_step": one * 1e3,
+                               "sample": f"the same B={batch} step on ONE thread, {n1} step(s)"}}
     best, n, loss = _oracle_steps(kind, batch, threads, 4, budget_s)
     one, n1, _ = _oracle_steps(kind, batch, 1, 2, 0.6 * budget_s)
     torch.set_num_threads(threads)
@@ -290,9 +300,10 @@ def roofline_objects(wl, batch, dtype="f32"):
     ms_copy = time_kernel_stream(copy_cold, iters=30)
     copy_gbs = 2 * batch * e0 * D * s / (ms_copy * 1e-3) / 1e9
     del msgs, outs
-    traffic, in_step = None, None
+    traffic, in_step, traffic_run = None, None, None
     try:   # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/*_traffic.json)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "aggregation_traffic.json")))["hbm_bytes_per_launch"]
+        tj = json.load(open(os.path.join(ROOT, "profiles", "aggregation_traffic.json")))
+        traffic, traffic_run = tj["hbm_bytes_per_launch"], tj.get("taken")
     except (OSError, KeyError, ValueError):
         pass
     try:   # the same kernel inside the profiled training step (profiles/summarize.py writes this next to the summary)
@@ -311,6 +322,11 @@ def roofline_objects(wl, batch, dtype="f32"):
             "avg_us_event_pair_per_launch": ms_pair * 1e3, "frac_event_pair_per_launch": gbs(ms_pair) / HBM_PEAK_GBS,
             "frac_cold": gbs(ms) / HBM_PEAK_GBS, "frac_warm": gbs(ms_warm) / HBM_PEAK_GBS, "avg_us_warm": ms_warm * 1e3,
             "frac_in_step": None if not in_step else in_step.get("frac"), "in_step": in_step,
+            # `traffic`, `frac_in_step` and `in_step` are NOT measured by this run: PMC counters need their own rocprofv3 passes and
+            # the in-step figure a kernel trace; they are read from the committed profiles of the same kernel
+            "source": {"achieved / frac / avg_us / frac_warm / cold_device_copy": "measured in this run (HIP events)",
+                       "traffic": None if traffic is None else f"committed profile profiles/aggregation_traffic.json (run {traffic_run}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                       "frac_in_step / in_step": None if not in_step else f"committed profile profiles/aggregation_in_step.json (from {in_step.get('source')}; rocprofv3 --kernel-trace of the training step)"},
             "cold_device_copy": {"GBps": copy_gbs, "frac_of_peak": copy_gbs / HBM_PEAK_GBS,
                                  "what": "torch copy_ of one message buffer into another under the same rotation (read + write bytes)",
                                  "aggregation_vs_copy": gbs(ms) / copy_gbs}}
@@ -501,6 +517,8 @@ def main():
                     help="f32: the reference's arithmetic (the headline line).  bf16: BSMS_BF16 precision of the U-Net "
                          "(BASELINE configs[2]/[4]; a SEPARATE line).  bf16_nodes: BSMS_BF16_NODES (node MLP in bf16 too)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=0,
+                    help="CPU baseline by SURVEY.md 8(d)'s protocol: 2 warm-up steps + best of K timed ones (default 0: a ~30 s sample)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the kernel micro-loops (for rocprofv3 --pmc passes)")
     ap.add_argument("--no-other-lines", action="store_true", help="skip the short timed regions of the other BASELINE configurations")
@@ -648,7 +666,7 @@ def main():
         if world == 1 and consistent and args.workload == "airfoil" and args.dtype == "f32" and args.batch == 8 and not args.no_other_lines:
             line["other_lines"] = other_lines(sim, data, line["config"]["loss"])
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cb = cpu_baseline(args.workload, args.batch)
+            line["cpu_baseline"] = cb = cpu_baseline(args.workload, args.batch, steps=args.cpu_baseline_steps)
             if consistent:   # same seed, same workload: the oracle's loss IS the expected GPU loss (parity at bench size)
                 rel = abs(cb["loss"] - line["config"]["loss"]) / abs(cb["loss"])
                 line["config"]["loss_vs_cpu_oracle_rel"] = rel

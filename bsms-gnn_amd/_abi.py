@@ -17,6 +17,7 @@ SIGNATURES = {
     "bsms_plan_create": (c_int, [c_void_p, c_i64, c_i64, PP]),
     "bsms_plan_set_pool": (c_int, [c_void_p, c_void_p, c_i64]),
     "bsms_plan_bind_edge_weights": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "bsms_plan_bound_edge_weights": (c_void_p, [c_void_p]),
     "bsms_plan_destroy": (c_int, [c_void_p]),
     "bsms_plan_pool_trim": (c_int, []),
     "bsms_plan_num_nodes": (c_i64, [c_void_p]),
@@ -48,6 +49,7 @@ SIGNATURES = {
                              c_void_p, c_void_p, PP, c_void_p]),
     "bsms_bsgmp_saved_bytes": (c_size_t, [PP, c_int, c_i64, c_i64, c_i64, c_int]),
     "bsms_bsgmp_work_bytes": (c_size_t, [PP, c_int, c_i64, c_i64, c_i64, c_int]),
+    "bsms_bsgmp_infer_work_bytes": (c_size_t, [PP, c_int, c_i64, c_i64, c_i64, c_int]),
     "bsms_bsgmp_fwd": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
     "bsms_bsgmp_fwd_ex": (c_int, [PP, PP, c_int, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, PP, c_void_p, c_void_p,

@@ -78,6 +78,7 @@ struct Work {
   float* skip[kMaxLevels];        // fwd: outputs of the down blocks; bwd: gradient arriving at the skip connections
   float* a[2];                    // two ping-pong level-0 sized buffers
   void* packs[2 * kMaxLevels + 1];  // inference: weight packs of every block (training keeps them in the saved blobs)
+  size_t fwd_bytes;               // the part a forward call touches (an inference call keeps its level inputs right behind it)
   size_t bytes;
 };
 Work carve_work(void* base, const Shape& s) {
@@ -85,7 +86,14 @@ Work carve_work(void* base, const Shape& s) {
   Work w{};
   size_t g = 0;
   for (int i = 0; i <= s.L; ++i) g = std::max(g, bsms_gmp_work_bytes(s.B, s.N[i], s.E[i], s.D, s.H));
+  // ---- what a FORWARD touches (training or inference) comes first: bsms_bsgmp_infer_work_bytes stops behind it, so a forward-only
+  // caller does not carry the backward's scratch sets (1.4 GB had become 4.7 GB at the airfoil batch-8 shape)
   w.gmp = c.bytes(g);
+  for (int i = 0; i < s.L; ++i) w.skip[i] = c.floats(size_t(s.B) * s.N[i] * s.D);
+  for (int k = 0; k < 2; ++k) w.a[k] = c.floats(size_t(s.B) * s.N[0] * s.D);
+  for (int k = 0; k <= 2 * s.L; ++k) w.packs[k] = c.bytes(gmp_pack_bytes(s.D, s.H));
+  w.fwd_bytes = c.off;
+  // ---- backward only
   w.gmp_b = c.bytes(s.L > 0 ? g : 0);
   // Per-block sets for the backward (round 5): 2L + 1 scratch sets sized for their own level -- 4.7 GB instead of 1.4 GB at the
   // airfoil batch-8 shape, out of 288 GB; larger shapes than the cap keep the two alternating sets -- remove the 2L - 1 barrier packets with which block k waited for the side lanes of block
@@ -101,9 +109,6 @@ Work carve_work(void* base, const Shape& s) {
     const int lv = level_of_block_bwd(k, s.L);
     w.gmp_blk[k] = !per_block ? nullptr : (k == 0 ? w.gmp : (k == 1 ? w.gmp_b : c.bytes(bsms_gmp_work_bytes(s.B, s.N[lv], s.E[lv], s.D, s.H))));
   }
-  for (int i = 0; i < s.L; ++i) w.skip[i] = c.floats(size_t(s.B) * s.N[i] * s.D);
-  for (int k = 0; k < 2; ++k) w.a[k] = c.floats(size_t(s.B) * s.N[0] * s.D);
-  for (int k = 0; k <= 2 * s.L; ++k) w.packs[k] = c.bytes(gmp_pack_bytes(s.D, s.H));
   w.bytes = c.off;
   return w;
 }
@@ -142,8 +147,14 @@ extern "C" size_t bsms_bsgmp_saved_bytes_p(const bsms_plan_t* const* plans, int 
 extern "C" size_t bsms_bsgmp_work_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden) {
   Shape s;
   if (make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_work_bytes")) return 0;
-  // inference keeps the level inputs in the scratch as well
-  return carve_work(nullptr, s).bytes + carve_saved(nullptr, s, false).bytes;
+  // (an inference call keeps its level inputs behind the forward part; covered, as the backward's sets are larger)
+  const Work w = carve_work(nullptr, s);
+  return std::max(w.bytes, w.fwd_bytes + carve_saved(nullptr, s, false).bytes);
+}
+extern "C" size_t bsms_bsgmp_infer_work_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden) {
+  Shape s;
+  if (make_shape(plans, L, B, D, p, hidden, &s, "bsgmp_infer_work_bytes")) return 0;
+  return carve_work(nullptr, s).fwd_bytes + carve_saved(nullptr, s, false).bytes;
 }
 
 extern "C" int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
@@ -171,7 +182,7 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
   hipStream_t st = as_stream(stream);
   const bool training = saved != nullptr;
   Work w = carve_work(work, s);
-  Saved v = training ? carve_saved(saved, s, true) : carve_saved(reinterpret_cast<char*>(work) + w.bytes, s, false);
+  Saved v = training ? carve_saved(saved, s, true) : carve_saved(reinterpret_cast<char*>(work) + w.fwd_bytes, s, false);
   const int64_t posB = pos_batch_stride ? B : 1;   // a 2-D pos is shared by the batch (ops/basic.py:87-88)
 
   // Two side lanes run ahead of the blocks; both are joined before level 1 starts:
@@ -188,7 +199,7 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
   SideLane *lane = nullptr, *lane0 = nullptr;
   auto packs_of = [&](int k) { return training ? nullptr : w.packs[k]; };
   if (L > 0) {
-    if (!pos_ok && ((rc = side_lane(&lane, 1)) || (rc = side_fork(lane, st)))) return rc;
+    if (!pos_ok && ((rc = side_lane(&lane, 1, st)) || (rc = side_fork(lane, st)))) return rc;
     for (int i = 0; i < L; ++i) {
       if (!pos_ok && (rc = bsms_edge_conv(plans[i], pos_l[i], posB, p, ew[i], 1, 1, v.pos[i + 1], lane->stream))) return rc;
       pos_l[i + 1] = v.pos[i + 1];
@@ -198,7 +209,7 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
       // two marks on the lane: the packs of the down path + bottom block (slot 0: waited for behind block 0) and those of the up path
       // (slot 1: waited for in front of the first up block).  One join behind block 0 made the caller's stream wait for all 2L
       // prepacks -- 130-160 us per step at D = 256, where a block's prepack takes 55 us (profiles/r05_surface_join_ab.txt)
-      if ((rc = side_lane(&lane0, 0)) || (rc = side_fork(lane0, st))) return rc;
+      if ((rc = side_lane(&lane0, 0, st)) || (rc = side_fork(lane0, st))) return rc;
       for (int k = 1; k <= 2 * L; ++k) {
         const int lv = level_of_block(k, L);
         if ((rc = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream, precision))) return rc;
@@ -252,8 +263,8 @@ extern "C" int bsms_bsgmp_bwd_p(const bsms_plan_t* const* plans, const float* co
 extern "C" int bsms_side_lanes_join(bsms_stream_t stream) {
   SideLane *lane0 = nullptr, *lane1 = nullptr;
   int rc;
-  if ((rc = side_lane(&lane0, 0)) || (rc = side_lane(&lane1, 1))) return rc;
   hipStream_t st = as_stream(stream);
+  if ((rc = side_lane(&lane0, 0, st)) || (rc = side_lane(&lane1, 1, st))) return rc;
   for (int slot = 0; slot < 2; ++slot)   // a slot nobody marked is an event that was never recorded: the wait is a no-op
     if ((!gmp_marks_chained() && (rc = side_wait_mark(lane0, slot, st))) || (rc = side_wait_mark(lane1, slot, st))) return rc;
   return BSMS_OK;
@@ -295,7 +306,7 @@ extern "C" int bsms_bsgmp_bwd_ev(const bsms_plan_t* const* plans, const float* c
   // this change the caller's stream idled 30-160 us per block at the join (the split-K weight gradients of a block
   // take longer than its gradient strand), ~1 ms of a 7.6 ms step.
   SideLane *lane0 = nullptr, *lane1 = nullptr;
-  if ((rc = side_lane(&lane0, 0)) || (rc = side_lane(&lane1, 1))) return rc;
+  if ((rc = side_lane(&lane0, 0, st)) || (rc = side_lane(&lane1, 1, st))) return rc;
   int nblk = 0;
   bool marked[2] = {false, false};   // slots this call has marked (gmp_bwd_core marks both lanes of its slot)
   auto run_block = [&](int level, const float* x, const float* g_in, int k, float* gx) -> int {

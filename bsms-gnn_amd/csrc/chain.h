@@ -266,7 +266,7 @@ bool edge_fused32_supported(int64_t D, int H, int64_t p, int precision);
 int launch_edge_fused32_bwd(EdgeFused32Args a, int* nwg_out, hipStream_t s);
 constexpr int kEdgeFusedMaxWg = 256;
 bool edge_fused_supported(int64_t D, int H, int64_t p, int precision);
-size_t edge_fused_part_floats();
+size_t edge_fused_part_floats(int64_t rows);   // for a launch over `rows` edge rows: one partial per workgroup, at most kEdgeFusedMaxWg
 int launch_edge_fused_bwd(EdgeFusedBwdArgs a, int* nwg_out, hipStream_t s);
 int launch_edge_fused_reduce(const float* part, int nwg, float* const dW[3], float* const db[3], hipStream_t s);
 

@@ -1560,13 +1560,7 @@ constexpr int resident_per_cu() { return NB <= 4 ? 4 : NB == 8 ? 2 : 1; }
 // 5-wave workgroup like an 8-wave one anyway (resident_per_cu), so the extra waves use slots that were empty.
 template <int NB>
 int chain_compute_waves(int64_t R) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
+  const int cus = device_cu_count();
   const int64_t slots = int64_t(cus) * resident_per_cu<NB>();
   if (NB < 8 || ceil_div(R, kTileRows) <= slots) return kComputeWaves;
   const int64_t need = ceil_div(R, slots * 16);   // waves per workgroup for one round
@@ -1575,27 +1569,12 @@ int chain_compute_waves(int64_t R) {
 
 template <int NB>
 unsigned persistent_grid(int64_t ntiles) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
+  const int cus = device_cu_count();
   return (unsigned)std::min<int64_t>(ntiles, int64_t(cus) * resident_per_cu<NB>());
 }
 
 
-inline int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
+inline int device_cus() { return device_cu_count(); }   // common.h: cached per device
 
 // Launch shape knobs.  Production values are the defaults; experiment builds read them from the environment for
 // same-box sweeps (BSMS_EDGE_CW, BSMS_EDGE_NL, BSMS_CHAIN_NL, BSMS_EDGE_CW16, BSMS_EDGE_NL16).
@@ -1689,8 +1668,8 @@ void pick_stream(int64_t ntiles, int cw, int nload_default, int& nload, int& nri
 
 template <int NB, int RB, bool SAVE>
 int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+  static DynLdsAttr attr_dev;
+  const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   const int cw = pick_edge_waves<NB, RB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
@@ -1698,8 +1677,8 @@ int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
   static const int lone = knob("BSMS_EDGE_LONE", 1);
   if (lone && a.ntiles <= device_cus() && !a.timing) {   // one round of workgroups: the variant that passes the chunk barrier early (stage_rb<LONE>)
-    static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE, true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+    static DynLdsAttr lattr_dev;
+  const hipError_t lattr = lattr_dev.ensure(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
     BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "edge_fwd: cannot reserve LDS (single-round build)");
     hipLaunchKernelGGL((k_edge_fwd<NB, RB, SAVE, true>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes(a.nring), s, a);
     BSMS_LAUNCH_CHECK();
@@ -1732,8 +1711,8 @@ bool launch_edge_fwd(ChainFwdArgs& a, hipStream_t s, int& rc) {
 
 template <int NB, int RB>
 int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+  static DynLdsAttr attr_dev;
+  const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   const int cw = pick_edge_waves<NB, RB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * RB * cw);
@@ -1741,8 +1720,8 @@ int launch_edge_bwd_t(ChainBwdArgs& a, hipStream_t s) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.ntiles, int64_t(device_cus()) * EdgeTile<NB, RB>::resident);
   static const int lone = knob("BSMS_EDGE_LONE", 1);
   if (lone && a.ntiles <= device_cus()) {   // see launch_edge_fwd_t
-    static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB, true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+    static DynLdsAttr lattr_dev;
+  const hipError_t lattr = lattr_dev.ensure(reinterpret_cast<const void*>(&k_edge_bwd<NB, RB, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
     BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "edge_bwd: cannot reserve LDS (single-round build)");
     hipLaunchKernelGGL((k_edge_bwd<NB, RB, true>), dim3(grid), dim3((cw + a.nload) * 64), Ring<NB>::lds_bytes(a.nring), s, a);
     BSMS_LAUNCH_CHECK();
@@ -1784,8 +1763,8 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
     a.wseq[a.nseq++] = a.wp[l];
     if (IN == IN_ROWS2 && l == 0) a.wseq[a.nseq++] = a.wp0b;
   }
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+  static DynLdsAttr attr_dev;
+  const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   if constexpr ((NB == 8 || NB == 16) && IN == IN_EDGE && OUT == OUT_LN) {
     int rc = BSMS_OK;
@@ -1809,8 +1788,8 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   bool launched = false;
   if constexpr (NB == 8 && IN == IN_EDGE) {   // the only instantiation with stamps
     if (a.timing) {
-      static const hipError_t tattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      static DynLdsAttr tattr_dev;
+  const hipError_t tattr = tattr_dev.ensure(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(tattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (timing build)");
       hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       launched = true;
@@ -1819,8 +1798,8 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
 #ifdef BSMS_EXPERIMENTS
   if constexpr (NB == 8 && IN == IN_ROWS2 && OUT == OUT_LN) {   // experiments: phase stamps of a single-round node chain (profiles/lone_timeline.py)
     if (a.timing && a.ntiles <= device_cus()) {
-      static const hipError_t tattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, true, false, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      static DynLdsAttr tattr_dev;
+  const hipError_t tattr = tattr_dev.ensure(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, true, false, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(tattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (timing build)");
       hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, true, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       launched = true;
@@ -1829,8 +1808,8 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
 #endif
   if constexpr ((NB == 8 || NB == 16) && (IN == IN_EDGE || IN == IN_ROWS2) && OUT == OUT_LN) {   // the bf16 arithmetic: edge MLP (BSMS_BF16), node MLP (BSMS_BF16_NODES)
     if (a.bf16 && !launched) {
-      static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      static DynLdsAttr battr_dev;
+  const hipError_t battr = battr_dev.ensure(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(battr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (bf16 build)");
       hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       launched = true;
@@ -1839,8 +1818,8 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   BSMS_REQUIRE(launched || !a.bf16, BSMS_E_UNSUPPORTED, "chain_fwd: bf16 precision is built for the edge and node MLPs at D = 128 / 256 only");
   if constexpr (NB >= 8) {   // one round of workgroups = a single wave per SIMD: the variant that prefetches its fragments (mfma_stage)
     if (!launched && a.ntiles <= device_cus()) {
-      static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, false, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      static DynLdsAttr lattr_dev;
+  const hipError_t lattr = lattr_dev.ensure(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, false, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (single-round build)");
       hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       launched = true;
@@ -1875,8 +1854,8 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   for (int k = 0; k < a.nstage; ++k) a.wseq[a.nseq++] = a.wpt[k];
   if (FIRST != F_NONE) a.wseq[a.nseq++] = a.wh0;
   if (FIRST == F_HEADS2) a.wseq[a.nseq++] = a.wh1;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+  static DynLdsAttr attr_dev;
+  const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve %zu bytes of LDS", Ring<NB>::lds_bytes(max_ring<NB>()));
   if constexpr (NB == 8 && (GIN == G_ROWS_LN || GIN == G_SMALL)) {   // small launches: the feature-split kernel (see launch_fwd_t)
     static const int fs_rows = knob("BSMS_FS_ROWS_BWD", kFsMaxRowsBwd);
@@ -1897,8 +1876,8 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
     if (launch_edge_bwd<NB>(a, s, rc)) return rc;
     a.ntiles = (int)ceil_div(a.R, 16 * cw);
     if (a.bf16) {
-      static const hipError_t battr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      static DynLdsAttr battr_dev;
+  const hipError_t battr = battr_dev.ensure(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(battr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve LDS (bf16 build)");
       hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       BSMS_LAUNCH_CHECK();
@@ -1907,8 +1886,8 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   }
   if constexpr ((NB == 8 || NB == 16) && GIN == G_ROWS_LN && FIRST == F_HEADS2) {   // node MLP of BSMS_BF16_NODES
     if (a.bf16) {
-      static const hipError_t nattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      static DynLdsAttr nattr_dev;
+  const hipError_t nattr = nattr_dev.ensure(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(nattr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve LDS (bf16 node build)");
       hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       BSMS_LAUNCH_CHECK();
@@ -1918,8 +1897,8 @@ int launch_bwd_t(const ChainBwdArgs& a0, hipStream_t s) {
   BSMS_REQUIRE(!a.bf16, BSMS_E_UNSUPPORTED, "chain_bwd: bf16 precision is built for the edge and node MLPs at D = 128 / 256 only");
   if constexpr (NB >= 8) {   // see launch_fwd_t
     if (a.ntiles <= device_cus()) {
-      static const hipError_t lattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, false, true>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ring<NB>::lds_bytes(max_ring<NB>()));
+      static DynLdsAttr lattr_dev;
+  const hipError_t lattr = lattr_dev.ensure(reinterpret_cast<const void*>(&k_chain_bwd<NB, GIN, FIRST, false, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "chain_bwd: cannot reserve LDS (single-round build)");
       hipLaunchKernelGGL((k_chain_bwd<NB, GIN, FIRST, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
       BSMS_LAUNCH_CHECK();

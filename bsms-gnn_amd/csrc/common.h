@@ -48,7 +48,7 @@ struct SideLane {
   hipEvent_t done_ev[2] = {nullptr, nullptr};   // "everything queued on the lane up to here has run", two slots
 };
 constexpr int kSideLanes = 2;
-int side_lane(SideLane** out, int which = 0);        // for the current device; `which` < kSideLanes
+int side_lane(SideLane** out, int which, hipStream_t caller);   // for the current device; `which` < kSideLanes; `caller`: see plan.hip (capture)
 int side_fork(SideLane* lane, hipStream_t main);     // side waits for main
 int side_join(SideLane* lane, hipStream_t main);     // main waits for side
 // Deferred join: side_mark records "the lane's work so far" into slot 0/1; side_wait_mark makes `main` wait for what
@@ -59,6 +59,35 @@ int side_mark(SideLane* lane, int slot);
 int side_wait_mark(SideLane* lane, int slot, hipStream_t main);
 int side_mark_chain(SideLane* a, SideLane* b, int slot);   // b's mark covers a's: wait for b only
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Per-DEVICE launch state: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the device that is current
+// when it is called, and the CU count is a property of that device -- a process driving several devices (not the one-process-per-GPU
+// layout of dp.py, but legal at the C ABI) must not reuse the first device's answers.  Both are cached per device index; the
+// races are benign (two threads may set the same attribute / read the same count twice).
+constexpr int kMaxDevices = 64;
+inline int current_device_index() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
+struct DynLdsAttr {
+  int state[kMaxDevices] = {};   // 0: not asked on this device yet; 1 + hipError_t afterwards
+  hipError_t ensure(const void* fn, int bytes) {
+    int& st = state[current_device_index()];
+    if (st == 0) st = 1 + int(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return hipError_t(st - 1);
+  }
+};
+inline int device_cu_count() {
+  static int cus[kMaxDevices] = {};
+  const int dev = current_device_index();
+  if (cus[dev] <= 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+    cus[dev] = v;
+  }
+  return cus[dev];
+}
 
 // ---- internal entry points shared between translation units (not part of the C ABI)
 // rowsum.hip: bsms_edge_conv + fused addend

@@ -561,14 +561,7 @@ __global__ __launch_bounds__(256) void k_ef_reduce(const float* part, int nwg, f
   }
 }
 
-int device_cus_ef() {
-  static const int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    return v;
-  }();
-  return n;
-}
+int device_cus_ef() { return device_cu_count(); }   // common.h: cached per device
 
 }  // namespace
 
@@ -577,12 +570,12 @@ namespace bsms {
 bool edge_fused_supported(int64_t D_, int H, int64_t p, int precision) {
   return precision != BSMS_F32 && D_ == 128 && H == 3 && p >= 1 && p <= 3;
 }
-size_t edge_fused_part_floats() { return size_t(kEdgeFusedMaxWg) * (DW_FLOATS + DB_FLOATS); }
+size_t edge_fused_part_floats(int64_t rows) { return size_t(std::min<int64_t>(ceil_div(rows, ST_ROWS), kEdgeFusedMaxWg)) * (DW_FLOATS + DB_FLOATS); }
 
 int launch_edge_fused_bwd(EdgeFusedBwdArgs a, int* nwg_out, hipStream_t s) {
   BSMS_REQUIRE(a.R < (int64_t(1) << 31) && a.p >= 1 && a.p <= 3, BSMS_E_UNSUPPORTED, "edge_fused_bwd: R = %lld, p = %d", (long long)a.R, a.p);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fused_bwd),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  static DynLdsAttr attr_dev;
+  const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_edge_fused_bwd), LDS_BYTES);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fused_bwd: cannot reserve %d bytes of LDS", LDS_BYTES);
   a.ntiles = int(ceil_div(a.R, ST_ROWS));
   const int nwg = int(std::min<int64_t>(a.ntiles, std::min(device_cus_ef(), kEdgeFusedMaxWg)));

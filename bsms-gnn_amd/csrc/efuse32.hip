@@ -463,14 +463,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   lds_barrier();   // the last pair is staged: the gradient waves finish behind this barrier
 }
 
-int device_cus_ef32() {
-  static const int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    return v;
-  }();
-  return n;
-}
+int device_cus_ef32() { return device_cu_count(); }   // common.h: cached per device
 
 }  // namespace
 
@@ -482,8 +475,8 @@ bool edge_fused32_supported(int64_t D_, int H, int64_t p, int precision) {
 
 int launch_edge_fused32_bwd(EdgeFused32Args a, int* nwg_out, hipStream_t s) {
   BSMS_REQUIRE(a.R < (int64_t(1) << 31) && a.p >= 1 && a.p <= 3, BSMS_E_UNSUPPORTED, "edge_fused32_bwd: R = %lld, p = %d", (long long)a.R, a.p);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fused32_bwd),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  static DynLdsAttr attr_dev;
+  const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_edge_fused32_bwd), LDS_BYTES);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fused32_bwd: cannot reserve %d bytes of LDS", LDS_BYTES);
   a.ntiles = int(ceil_div(a.R, ST_ROWS));
   const int nwg = int(std::min<int64_t>(a.ntiles, std::min(device_cus_ef32(), kEdgeFusedMaxWg)));

@@ -224,14 +224,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   }
 }
 
-int device_cus() {
-  static const int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    return v;
-  }();
-  return n;
-}
+int device_cus() { return device_cu_count(); }   // common.h: cached per device
 
 }  // namespace
 
@@ -243,8 +236,8 @@ bool edge_fwd_res_supported(int64_t D_, int H, int64_t p, int precision) {
 
 int launch_edge_fwd_res(EdgeFwdResArgs a, hipStream_t s) {
   BSMS_REQUIRE(a.R < (int64_t(1) << 31) && a.p >= 1 && a.p <= 3, BSMS_E_UNSUPPORTED, "edge_fwd_res: R = %lld, p = %d", (long long)a.R, a.p);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_fwd_res),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  static DynLdsAttr attr_dev;
+  const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_edge_fwd_res), LDS_BYTES);
   BSMS_REQUIRE(attr == hipSuccess, BSMS_E_HIP, "edge_fwd_res: cannot reserve %d bytes of LDS", LDS_BYTES);
   a.ntiles = int(ceil_div(a.R, 16));
   const int nwg = int(std::min<int64_t>(ceil_div(a.ntiles, WAVES), device_cus()));

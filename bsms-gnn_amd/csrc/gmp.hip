@@ -119,6 +119,7 @@ struct GmpWork {
   float* ef_part;   // fused edge backward: per-workgroup partial weight gradients (efuse.hip)
   size_t bytes;
 };
+bool edge_fused_possible(int64_t D, int H);   // below: use_edge_fused for any precision
 GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H) {
   Carver c(base);
   GmpWork w{};
@@ -132,7 +133,9 @@ GmpWork carve_gmp_work(void* base, int64_t B, int64_t N, int64_t E, int64_t D, i
   w.wg2 = c.take_bytes(wgrad_work_bytes((int)D, 0));   // second split-K area: two wgrad launches run concurrently
   w.sw_bytes = small_wgrad_work_bytes_rows((int)D, B * N);   // one partial block per workgroup of the fused scatter kernel
   w.sw = c.take_bytes(w.sw_bytes);
-  w.ef_part = (D == 128 && H == 3) ? c.take(edge_fused_part_floats()) : nullptr;
+  // one partial per workgroup of the fused edge backward, where a precision of this build can take it (the size query has no
+  // precision argument): min(tiles, CUs) x 198 KB instead of 52 MB for every set
+  w.ef_part = edge_fused_possible(D, H) ? c.take(edge_fused_part_floats(int64_t(re))) : nullptr;
   w.bytes = c.off;
   return w;
 }
@@ -174,6 +177,8 @@ constexpr int g_edge_fused32 = 0;
 bool use_edge_fused(int64_t D, int H, int precision) {
   return precision == BSMS_F32 ? (g_edge_fused32 && edge_fused32_supported(D, H, 1, precision)) : (g_edge_fused && edge_fused_supported(D, H, 1, precision));
 }
+
+bool edge_fused_possible(int64_t D, int H) { return use_edge_fused(D, H, BSMS_F32) || use_edge_fused(D, H, BSMS_BF16) || use_edge_fused(D, H, BSMS_BF16_NODES); }
 
 int check_gmp(const bsms_plan_t* plan, int64_t B, int64_t D, int64_t p, int H, const char* who) {
   BSMS_REQUIRE(plan != nullptr, BSMS_E_INVALID_ARG, "%s: plan is null", who);
@@ -481,7 +486,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   hipStream_t ws = s;
   LaneScope scope1(s, defer_slot), scope2(s, defer_slot);
   if (overlap) {
-    if ((rc = side_lane(&lane)) || (rc = side_fork(lane, s))) return rc;
+    if ((rc = side_lane(&lane, 0, s)) || (rc = side_fork(lane, s))) return rc;
     ws = lane->stream;
     scope1.lane = lane;
   }
@@ -525,7 +530,7 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   const bool overlap2 = overlap && !(g_debug_flags & 32);
   bool lane2_forked = false;   // its first fork is only needed by the unfused small-wgrad path; the fused path forks once, below
   if (overlap2) {
-    if ((rc = side_lane(&lane2, 1))) return rc;
+    if ((rc = side_lane(&lane2, 1, s))) return rc;
     s2 = lane2->stream;
   }
   // gradient of the first edge Linear w.r.t. the two per-node projections -- and, in the same pass over gE[0], the
@@ -766,7 +771,7 @@ extern "C" int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, i
   // joins later (bsms_side_lanes_join) -- the fused step runs the decoder's weight gradients under the U-Net's first block
   if (flags & BSMS_BWD_DEFER_JOIN) {
     SideLane* lane = nullptr;
-    if ((rc = side_lane(&lane, 0)) || (rc = side_fork(lane, s))) return rc;
+    if ((rc = side_lane(&lane, 0, s)) || (rc = side_fork(lane, s))) return rc;
     s = lane->stream;
   }
   WgradJob jobs[kMaxWgradJobs] = {};
@@ -796,7 +801,7 @@ extern "C" int bsms_mlp_bwd_ex(const float* x, const float* grad_y, int64_t R, i
   if (rc) return rc;
   if (flags & BSMS_BWD_DEFER_JOIN) {   // visible to bsms_side_lanes_join even if nothing else uses the lane afterwards
     SideLane* lane = nullptr;
-    if ((rc = side_lane(&lane, 0)) || (rc = side_mark(lane, 0))) return rc;
+    if ((rc = side_lane(&lane, 0, s)) || (rc = side_mark(lane, 0))) return rc;
   }
   return BSMS_OK;
 }

@@ -55,7 +55,11 @@ static bool can_overtake(hipStream_t a, hipStream_t b) {
 // a non-blocking stream that shares its hardware queue neither with the legacy default stream (what PyTorch runs on) nor with the
 // lanes that exist already; streams that failed the probe are kept until one passes (each raises the reference count of the queue
 // it sits on, so the next creation goes elsewhere), then destroyed
-static int create_lane_stream(hipStream_t* out, const SideLane* lanes, int which) {
+static int create_lane_stream(hipStream_t* out, const SideLane* lanes, int which, bool probe) {
+  if (!probe) {   // the caller is capturing a HIP graph: hipMalloc / legacy-stream fills / event synchronisation would invalidate the capture
+    BSMS_HIP_CHECK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return BSMS_OK;
+  }
   std::vector<hipStream_t> ballast;
   hipStream_t st = nullptr;
   for (int attempt = 0; attempt < 6; ++attempt) {
@@ -72,7 +76,11 @@ static int create_lane_stream(hipStream_t* out, const SideLane* lanes, int which
   return BSMS_OK;
 }
 
-int side_lane(SideLane** out, int which) {
+// `caller`: the stream the entry point was called with.  If it is being CAPTURED the lane is created without the hardware-queue
+// probe (the probe allocates, fills on the legacy stream and synchronises an event -- none of it legal under a
+// capture); such a lane may share a hardware queue with another stream, which costs overlap, never correctness.  Callers that
+// capture should run one eager call first (the Python paths do: their warm-up steps), as include/bsms_hip.h says.
+int side_lane(SideLane** out, int which, hipStream_t caller) {
   int dev = 0;
   BSMS_HIP_CHECK(hipGetDevice(&dev));
   BSMS_REQUIRE(dev >= 0 && dev < 64 && which >= 0 && which < kSideLanes, BSMS_E_UNSUPPORTED, "side_lane: device %d lane %d", dev, which);
@@ -86,7 +94,12 @@ int side_lane(SideLane** out, int which) {
       BSMS_HIP_CHECK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, atoi(e) < 0 ? least : greatest));
     } else
 #endif
-    { int rc_ = create_lane_stream(&l.stream, g_lanes[dev], which); if (rc_) return rc_; }
+    {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(caller, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }   // cannot tell: do not risk a capture
+      int rc_ = create_lane_stream(&l.stream, g_lanes[dev], which, cap == hipStreamCaptureStatusNone);
+      if (rc_) return rc_;
+    }
     // same-device stream ordering only: no timing, and no system-scope fence when an event completes (the kernels'
     // own end-of-kernel release / start-of-kernel acquire make their data visible device-wide; the extra fence is for
     // hosts and other devices reading behind the event, which nothing here does)

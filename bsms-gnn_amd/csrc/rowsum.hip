@@ -602,7 +602,7 @@ extern "C" int bsms_plan_bind_edge_weights(bsms_plan_t* p, const float* ew, bsms
   // they are -- kernels still queued on other streams and captured HIP graphs have their pointers baked in --
   // and this tensor takes the unbound path of bsms_edge_conv (same sums in the same order, two dependent loads more per row).
   if (p->w_bound && p->w_bound != ew) return BSMS_OK;
-  if (p->w_bound == ew) return BSMS_OK;   // nothing to do: the copies were gathered from this tensor (mesh-static weights)
+  if (p->w_bound == ew) return BSMS_OK;   // nothing to do: the copies were gathered from this tensor (mesh-static weights; refresh = bind NULL, then bind again)
   const int64_t n = std::max(p->Ek, p->Ep);
   if (n > 0) {
     hipLaunchKernelGGL(k_bind_ew, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), ew, p->k_eid, p->k_w,
@@ -612,6 +612,8 @@ extern "C" int bsms_plan_bind_edge_weights(bsms_plan_t* p, const float* ew, bsms
   p->w_bound = ew;
   return BSMS_OK;
 }
+
+extern "C" const float* bsms_plan_bound_edge_weights(const bsms_plan_t* p) { return p ? p->w_bound : nullptr; }
 
 extern "C" int bsms_edge_conv(const bsms_plan_t* p, const float* x, int64_t B, int64_t D, const float* ew,
                               int aggregating, int pooled, float* out, bsms_stream_t stream) {

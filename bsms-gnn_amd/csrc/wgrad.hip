@@ -764,25 +764,25 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
   tab.colsums = tab.partials + size_t(kMaxTiles) * TB * TB;
   tab.timing = g_wgrad_timing;
   const size_t lds = size_t(2) * 6 * PLANE * sizeof(short);   // 108 KB: 2 x [G|A][3 planes][32 rows][288 B]
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<false>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  static const hipError_t attr_t = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static DynLdsAttr attr_dev;
+  const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_wgrad<false>), (int)lds);
+  static DynLdsAttr attr_t_dev;
+  const hipError_t attr_t = attr_t_dev.ensure(reinterpret_cast<const void*>(&k_wgrad<true>), (int)lds);
   BSMS_REQUIRE(attr == hipSuccess && attr_t == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS", lds);
   if (h2) {
-    static const hipError_t attr_h = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<false, false, true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsAttr attr_h_dev;
+  const hipError_t attr_h = attr_h_dev.ensure(reinterpret_cast<const void*>(&k_wgrad<false, false, true>), (int)lds);
     BSMS_REQUIRE(attr_h == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (fp16 x 2 build)", lds);
     hipLaunchKernelGGL((k_wgrad<false, false, true>), dim3(first), dim3(WG_THREADS), lds, s, tab);
   } else if (bf && [] { const char* e = getenv("BSMS_WGRAD_BF64"); return !e || atoi(e) != 0; }()) {
     const size_t lds_b = size_t(2) * 2 * PLANE2 * sizeof(short);   // 72 KB: 2 x [G|A][64 rows][288 B]
-    static const hipError_t attr_b64 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf64),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    static DynLdsAttr attr_b64_dev;
+  const hipError_t attr_b64 = attr_b64_dev.ensure(reinterpret_cast<const void*>(&k_wgrad_bf64), (int)lds_b);
     BSMS_REQUIRE(attr_b64 == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (bf16 build, 64-row chunks)", lds_b);
     hipLaunchKernelGGL(k_wgrad_bf64, dim3(first), dim3(WG_THREADS), lds_b, s, tab);
   } else if (bf) {
-    static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<false, true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsAttr attr_b_dev;
+  const hipError_t attr_b = attr_b_dev.ensure(reinterpret_cast<const void*>(&k_wgrad<false, true>), (int)lds);
     BSMS_REQUIRE(attr_b == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (bf16 build)", lds);
     hipLaunchKernelGGL((k_wgrad<false, true>), dim3(first), dim3(WG_THREADS), lds, s, tab);
   } else if (tab.timing) hipLaunchKernelGGL(k_wgrad<true>, dim3(first), dim3(WG_THREADS), lds, s, tab);

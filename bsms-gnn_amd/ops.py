@@ -580,7 +580,7 @@ def _bsgmp_infer(h, pos, plans, ews, hidden, params, session=None, prec=0):
     pl, keep_pl = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in plans])
     ewp, keep_ew = _abi.ptr_array([e.data_ptr() for e in ews])
     out = torch.empty_like(h)
-    nbytes = L.bsms_bsgmp_work_bytes(pl, depth, B, D, p, hidden)
+    nbytes = L.bsms_bsgmp_infer_work_bytes(pl, depth, B, D, p, hidden)    # forward-only: without the backward's per-block scratch sets
     reuse = 0
     if session is not None:
         reuse = session.flags(params, plans, B, nbytes, h.device, geom=(D, p, hidden, prec, pos_bstride))
@@ -591,6 +591,32 @@ def _bsgmp_infer(h, pos, plans, ews, hidden, params, session=None, prec=0):
     _abi.check(L.bsms_bsgmp_fwd_p(pl, ewp, depth, h.data_ptr(), pos.data_ptr(), B, D, p, pos_bstride, hidden, pp,
                                   out.data_ptr(), None, work.data_ptr(), reuse, prec, _stream()), "bsms_bsgmp_fwd(inference)")
     return out
+
+
+def _bind_edge_weights(plan, ew):
+    """bsms_plan_bind_edge_weights with the bookkeeping its by-ADDRESS binding needs.  Returns the tensor the
+    caller should pass as this level's edge weights from now on.
+
+    * The plan object keeps the tensor the C side is bound to alive in `_ew_bound` -- and ONLY that one: the library keeps an
+      existing binding to another pointer (captured graphs have the gathered copies baked in), so `_ew_bound` is replaced only
+      when the library reports the new pointer as bound.  Dropping the bound tensor would let the caching allocator hand its
+      address to another weight tensor of the same size, which the fast path would then take for the bound one.
+    * A plan that is already bound to another tensor with the SAME content (a coarse plan whose level-0 plan was evicted from
+      the cache and rebuilt: same hierarchy, same weights, new tensors) hands back the bound tensor, so the rebuilt chain
+      keeps the compact transition lists instead of falling back to index chasing for good.  One device compare per level
+      and rebuilt hierarchy, never on a step's path."""
+    L = _abi.lib()
+    _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, ew.data_ptr(), _stream()), "bsms_plan_bind_edge_weights")
+    bound = L.bsms_plan_bound_edge_weights(plan.handle) or 0
+    if bound == ew.data_ptr():
+        held = getattr(plan, "_ew_bound", None)
+        if held is None or held.data_ptr() != bound:
+            plan._ew_bound = ew
+        return ew
+    held = getattr(plan, "_ew_bound", None)
+    if held is not None and held.data_ptr() == bound and held.shape == ew.shape and held.device == ew.device and torch.equal(held, ew):
+        return held
+    return ew
 
 
 class BSGMP(nn.Module):
@@ -632,12 +658,11 @@ class BSGMP(nn.Module):
             for plan, ids in zip(plans, m_ids):
                 ew, w_full = self.edge_conv.cal_ew(w, None, plan=plan)
                 w = w_full[ids]
-                ews.append(ew)
                 # the weights are mesh-static and cached with the plan: gather them once into the slot orders of the pooled
                 # transitions (restrict / prolong then read compact index + weight streams, csrc/rowsum.hip)
                 if os.environ.get("BSMS_BIND_EW", "1") == "1":     # ("0": same-box A/B of the unbound index-chasing path, profiles/ab_env.sh)
-                    _abi.check(_abi.lib().bsms_plan_bind_edge_weights(plan.handle, ew.data_ptr(), _stream()), "bsms_plan_bind_edge_weights")
-                    plan._ew_bound = ew        # the binding is by ADDRESS: the plan keeps the tensor alive, so the address cannot be recycled while bound
+                    ew = _bind_edge_weights(plan, ew)
+                ews.append(ew)
             plans[0]._ew_chain = (key, ews)                      # keyed by plan uids: no reference cycle through the plans
         return ews
 

@@ -75,8 +75,12 @@ class FusedStep:
         return (isinstance(model, BSMS_Simulator) and not model.process.per_block
                 and all(p.requires_grad for p in [*model.encode.parameters(), *model.process.parameters(), *model.decode.parameters()]))
 
+    collectives_at_world_one = False     # tests: issue the step's collectives in a process group of ONE rank as well (a sum over one
+                                         # rank is the identity) -- the only way to run the RCCL path on a single-GPU box
+
     def _world(self):
-        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        w = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        return 2 if (w == 1 and self.collectives_at_world_one and dist.is_available() and dist.is_initialized()) else w
 
     def _unpack(self, data, consistent):
         if consistent:

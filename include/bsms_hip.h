@@ -19,9 +19,11 @@
  *     overlap its weight-gradient kernels with its gradient scatters (forked from and joined back into
  *     `stream` inside the call, also legal under HIP-graph capture).
  *     The FIRST call that needs a side stream creates it and checks once, with a few device fills on a temporary
- *     64 MB allocation (~1 ms, outside any graph capture), that it does not share its hardware queue with the default
- *     stream or the other side stream -- HIP places streams on four hardware queues and two streams on one queue
- *     run in order.
+ *     64 MB allocation (~1 ms), that it does not share its hardware queue with the default stream or the other side
+ *     stream -- HIP places streams on four hardware queues and two streams on one queue run in order.
+ *     If `stream` is being CAPTURED at that first call the check is skipped (it allocates and synchronises, which would
+ *     invalidate the capture): the side stream is created plainly and may share a queue -- less overlap, same results.
+ *     Run one eager call before capturing to get the checked streams.
  *   - Arithmetic: fp32 in, fp32 out, fp32 accumulation.  Matrix products run on the f16 matrix cores as three
  *     partial products of two-way fp16 splits (11 + 11 significand bits) of power-of-two-scaled fp32 operands.
  *     Forward and input-gradient products scale per activation ROW and per weight MATRIX: the result is at least as
@@ -106,8 +108,14 @@ int bsms_plan_set_pool(bsms_plan_t* plan, const int64_t* ids_host, int64_t Nk);
  * guarantees that the content of `ew` is unchanged for as long as it passes that pointer; ew = NULL unbinds.  Results
  * are bit-identical to the unbound path.  A new bsms_plan_set_pool unbinds.  A plan already bound to ANOTHER non-null
  * pointer keeps that binding (captured HIP graphs and kernels still queued have the gathered copies baked in); the new
- * tensor then simply takes the unbound path.  To move a binding: bind NULL first, once nothing uses the old one. */
+ * tensor then simply takes the unbound path.  To move a binding: bind NULL first, once nothing uses the old one.
+ * Binding the pointer a plan is ALREADY bound to is a no-op (the copies are not gathered again): after changing the
+ * content of `ew` in place, bind NULL and then `ew` again to refresh them.  The binding is by ADDRESS: the caller keeps
+ * the bound tensor alive (and its address unrecycled) until it unbinds or destroys the plan;
+ * bsms_plan_bound_edge_weights returns the pointer a plan is bound to (NULL: unbound) so that a host wrapper can tell
+ * whether its bind call took effect and which tensor it has to keep alive. */
 int bsms_plan_bind_edge_weights(bsms_plan_t* plan, const float* ew, bsms_stream_t stream);
+const float* bsms_plan_bound_edge_weights(const bsms_plan_t* plan);
 int bsms_plan_destroy(bsms_plan_t* plan);
 int bsms_plan_pool_trim(void);
 int64_t bsms_plan_num_nodes(const bsms_plan_t* plan);
@@ -212,6 +220,10 @@ int bsms_gmp_bwd(const bsms_plan_t* plan, const float* x, const float* pos, cons
  * BSMS.py:96-101), each block laid out as for bsms_gmp_fwd.  `saved` = NULL selects inference. */
 size_t bsms_bsgmp_saved_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden);
 size_t bsms_bsgmp_work_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden);
+/* `work` size for callers that only ever run INFERENCE forwards (saved == NULL; rollout_utils.py:14-64) with this buffer:
+ * the forward's part of the layout without the backward's per-block scratch sets (airfoil batch 8: 1.4 GB against 4.7 GB).
+ * A buffer of bsms_bsgmp_work_bytes serves inference calls too. */
+size_t bsms_bsgmp_infer_work_bytes(const bsms_plan_t* const* plans, int L, int64_t B, int64_t D, int64_t p, int hidden);
 int bsms_bsgmp_fwd(const bsms_plan_t* const* plans, const float* const* ew, int L, const float* h, const float* pos,
                    int64_t B, int64_t D, int64_t p, int64_t pos_batch_stride, int hidden,
                    const float* const* params, float* out, void* saved, void* work, bsms_stream_t stream);

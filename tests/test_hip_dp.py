@@ -249,3 +249,76 @@ def test_overlap_self_check_decides_once_and_identically(tmp_path):
         assert torch.equal(r0["flats"][k], r1["flats"][k]) and r0["losses"][k] == r1["losses"][k]      # ranks agree bit for bit
         assert torch.equal(r0["flats"][k], r0["flats"][0])                                             # plain == overlapped form
     print(f"\nself-check on gloo: plain {r0['ms']['plain']:.2f} ms, overlapped {r0['ms']['overlapped']:.2f} ms per step -> overlap {'kept' if r0['use'] else 'dropped'}")
+
+
+def _rccl_world1_worker(rank, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from conftest import Golden
+    from oracle import bsms_oracle as ro
+    import bsms_gnn_amd as eng
+    from bsms_gnn_amd import _abi
+
+    z, graphs = Golden("sim"), Golden("graphs")
+    es, ids = graphs.levels("del300")
+    cfg = ro.make_cfg(2, 32, 3, 3, 2)
+    c = lambda t: t.cuda()
+    data = (c(z.t("node_in")), c(z.t("tar")), c(z.t("mask")), [c(e.unsqueeze(0)) for e in es], [c(i.unsqueeze(0)) for i in ids])
+
+    def run(distributed, overlapped):
+        sim = eng.BSMS_Simulator(cfg)
+        sim.load_state_dict(z.state_dict())
+        sim = sim.cuda()
+        if not distributed:                                   # the non-distributed step: no process group in sight of FusedStep
+            grads = eng.GradBuckets(list(sim.parameters()), 64 << 10)
+            fused = eng.FusedStep(sim, grads, None)
+            fused._world = lambda: 1
+        else:
+            engine = eng.DataParallel(sim, bucket_bytes=64 << 10)
+            fused, grads = engine.fused, engine.grads
+            fused.collectives_at_world_one = True             # a one-rank group: every collective is issued, every sum is the identity
+            fused.force_overlap = overlapped
+            fused.overlap_allreduce = overlapped
+        losses, flats = [], []
+        for _ in range(3):
+            losses.append(fused(data, True).detach().cpu())
+            flats.append(grads.flat.clone().cpu())
+        torch.cuda.synchronize()
+        return losses, flats, fused
+
+    base_l, base_f, _ = run(False, False)
+    plain_l, plain_f, _ = run(True, False)
+    over_l, over_f, fused = run(True, True)
+    assert fused._comm is not None and fused._overlap is not None            # the overlapped path ran: comm stream, per-block events
+    assert len(fused.grads.buckets) > 3 and any(e is not None for e in fused._overlap["sched"])
+    ovl = _abi.lib().bsms_streams_overlap(fused._comm.cuda_stream, torch.cuda.current_stream().cuda_stream)
+    torch.save({"backend": dist.get_backend(), "base_l": base_l, "base_f": base_f, "plain_l": plain_l, "plain_f": plain_f,
+                "over_l": over_l, "over_f": over_f, "streams_overlap": int(ovl)}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_world_one_smoke(tmp_path):
+    """The RCCL code path on the one GPU a test box has: `init_process_group("nccl", world_size=1)`,
+    DataParallel's broadcast-free construction, then three FusedStep steps in the plain form (two-scalar loss all-reduce + ONE
+    all-reduce of the flat gradient buffer) and three in the overlapped form (`bsms_bsgmp_bwd_ev` events -> `comm.wait_event` ->
+    `all_reduce(async_op=True)` per bucket on the communication stream -> `work.wait()` -> `main.wait_stream(comm)`), plus
+    `bsms_streams_overlap(comm, main)`.  A sum over one rank is the identity, so all three must equal the non-distributed step
+    BIT FOR BIT.  This proves that the RCCL library loads, a communicator is created and the stream / event choreography is
+    legal on gfx950 -- it says NOTHING about scaling (replaces the DataParallel wrap of trainer/trainer.py:15-18)."""
+    port = 29800 + os.getpid() % 1500
+    out = str(tmp_path / "rccl1.pt")
+    mp.start_processes(_rccl_world1_worker, args=(port, out), nprocs=1, join=True, start_method="spawn")
+    r = torch.load(out)
+    assert r["backend"] == "nccl"
+    for k in range(3):
+        assert torch.equal(r["plain_l"][k], r["base_l"][k]) and torch.equal(r["over_l"][k], r["base_l"][k]), k
+        assert torch.equal(r["plain_f"][k], r["base_f"][k]), ("plain form", k)
+        assert torch.equal(r["over_f"][k], r["base_f"][k]), ("overlapped form", k)
+    assert r["streams_overlap"] in (0, 1)
+    print(f"\n[rccl world 1] backend {r['backend']}, comm stream overtakes the caller's stream: {bool(r['streams_overlap'])}; "
+          f"loss {float(r['base_l'][0]):.7f}")

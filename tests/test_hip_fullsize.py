@@ -16,6 +16,8 @@ Tolerances (BASELINE.json north_star: 1e-5 relative fp32)
     and which side of the kink they land on differs between ANY two fp32 summation orders -- so "GPU within 1e-5 of
     CPU fp32" is not a property even two runs of the reference on different BLAS builds have.  What is required:
         e_gpu(p) = max|g_gpu - g_64| / max|g_64| ,  e_cpu(p) likewise for the fp32 oracle
+        e_cpu = the fp32 oracle run TWICE, on all host threads and on one thread (two summation orders of the same arithmetic);
+        every statistic below takes the LARGER of the two runs' values (round 6)
         (a) worst tensor:    max_p e_gpu            <= max(1e-5, 1.5 * max_p e_cpu)
         (b) typical tensor:  median_p e_gpu         <= max(1e-5, 1.5 * median_p e_cpu)
         (c) tail:            90th percentile e_gpu  <= max(1e-5, 1.5 * 90th percentile e_cpu)
@@ -24,8 +26,9 @@ Tolerances (BASELINE.json north_star: 1e-5 relative fp32)
     i.e. the engine's distance to the exact gradient has the same distribution over the parameter tensors as the
     reference's own fp32 path.  (Rounds 1-3 allowed 3x / 2x / 2x; the measured ratios are 1.0-1.4 on the BASELINE
     configurations.  The depth-7 strip at B=4 -- few rows per coarse level, so few independent kink events -- measured a
-    median ratio of 1.63 in round 4 and 0.22 in round 5 -- the oracle's own fp32 run moves with the host's thread count --
-    and keeps 2x for (b).)  A per-tensor ratio is not meaningful (which tensors a near-zero ReLU input lands in is
+    median ratio of 1.63 in round 4 and 0.22 in round 5 against a single oracle run, whose own distance moves with the host's
+    thread count; rounds 4-5 therefore allowed 2x for (b) there.  Since round 6 the yardstick is two oracle runs and every
+    configuration uses 1.5; the measured ratios are printed and recorded in profiles/r06_tests.txt.)  A per-tensor ratio is not meaningful (which tensors a near-zero ReLU input lands in is
     random for both implementations), and the factors allow for the fact that ONE flipped mask perturbs the gradient
     of every layer upstream of it, so the per-tensor errors of a run are strongly correlated (few independent events).
     Measured on MI355X (gpu | cpu32, worst / median): airfoil B=8 9.4e-5 / 1.0e-5 | 9.3e-5 / 8.1e-6; cylinder B=8
@@ -96,6 +99,13 @@ def run_config(eng, kind, batch, layout, mesh=None, cfg=None):
     t32 = time.perf_counter() - t0
     _, loss64, g64 = _oracle_step(ref64, _to(cpu_data, _f64), consistent)
     t64 = time.perf_counter() - t0 - t32
+    # the SAME fp32 oracle on one thread: another summation order of the same arithmetic (round 6; the yardstick of `check`)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        _, _, g32_one = _oracle_step(ref32, cpu_data, consistent)
+    finally:
+        torch.set_num_threads(nthreads)
 
     pred = mine(gpu_data, consistent, False)
     tar, mask = (gpu_data[1], gpu_data[2]) if consistent else (gpu_data[0].y.unsqueeze(0), gpu_data[0].mask.unsqueeze(0))
@@ -104,10 +114,12 @@ def run_config(eng, kind, batch, layout, mesh=None, cfg=None):
     torch.cuda.synchronize()
     gg = {k: p.grad.detach().cpu() for k, p in mine.named_parameters() if p.grad is not None}
     return dict(pred=pred.detach().cpu(), pred32=pred32, loss=float(loss.detach()), loss32=loss32, loss64=loss64,
-                gg=gg, g32=g32, g64=g64, t32=t32, t64=t64, levels=wl["levels"])
+                gg=gg, g32=g32, g32_one=g32_one, g64=g64, t32=t32, t64=t64, levels=wl["levels"])
 
 
-def check(r, tag, f_worst=1.5, f_median=1.5, f_p90=1.5, f_direct=2.5):
+def check(r, tag):
+    F_WORST = F_MEDIAN = F_P90 = 1.5     # one set of factors for every configuration (round 6: no per-test overrides)
+    F_DIRECT = 2.5
     # ---- forward: element-wise and max-norm, against the fp32 oracle
     a, b = r["pred"].double(), r["pred32"].double()
     scale, rms = float(b.abs().max()), float(b.pow(2).mean().sqrt())
@@ -117,22 +129,31 @@ def check(r, tag, f_worst=1.5, f_median=1.5, f_p90=1.5, f_direct=2.5):
     assert not bool(bad.any()), (tag, "pred element-wise", int(bad.sum()))
     assert abs(r["loss"] - r["loss32"]) <= 1e-5 * abs(r["loss32"]), (tag, r["loss"], r["loss32"])
     # ---- gradients: three-way against fp64 (criterion in the module docstring)
-    assert set(r["gg"]) == set(r["g32"]) == set(r["g64"]), "a parameter is missing its gradient"
+    assert set(r["gg"]) == set(r["g32"]) == set(r["g64"]) == set(r["g32_one"]), "a parameter is missing its gradient"
     keys = sorted(r["g64"])
     e_gpu = np.array([_rel(r["gg"][k], r["g64"][k]) for k in keys])
-    e_cpu = np.array([_rel(r["g32"][k], r["g64"][k]) for k in keys])
+    e_cpuN = np.array([_rel(r["g32"][k], r["g64"][k]) for k in keys])        # the oracle on all threads
+    e_cpu1 = np.array([_rel(r["g32_one"][k], r["g64"][k]) for k in keys])    # the oracle on one thread
     direct = np.array([_rel(r["gg"][k], r["g32"][k]) for k in keys])
     worst = int(np.argmax(e_gpu))
-    p90g, p90c = np.percentile(e_gpu, 90), np.percentile(e_cpu, 90)
+    # Yardstick = the LARGER of the fp32 oracle's two distances to fp64, statistic by statistic: which near-zero ReLU inputs flip
+    # is a property of the summation order, the oracle has (at least) these two, and the engine is a third
+    y_worst = max(e_cpuN.max(), e_cpu1.max())
+    y_median = max(np.median(e_cpuN), np.median(e_cpu1))
+    y_p90 = max(np.percentile(e_cpuN, 90), np.percentile(e_cpu1, 90))
+    p90g = np.percentile(e_gpu, 90)
     print(f"\n[{tag}] levels {r['levels']}\n  oracle fp32 {r['t32']:.1f} s, fp64 {r['t64']:.1f} s; loss gpu {r['loss']:.7f} "
           f"cpu32 {r['loss32']:.7f} f64 {r['loss64']:.7f}; pred max-norm {float(diff.max()) / scale:.2e}\n"
-          f"  grads vs fp64 over {len(keys)} tensors: gpu worst {e_gpu.max():.2e} ({keys[worst]}) median {np.median(e_gpu):.2e} | "
-          f"cpu32 worst {e_cpu.max():.2e} median {np.median(e_cpu):.2e} | gpu-vs-cpu32 worst {direct.max():.2e} "
-          f"median {np.median(direct):.2e} | p90 gpu {p90g:.2e} cpu32 {p90c:.2e}")
-    assert e_gpu.max() <= max(1e-5, f_worst * e_cpu.max()), (tag, "worst tensor", keys[worst], e_gpu.max(), e_cpu.max())
-    assert np.median(e_gpu) <= max(1e-5, f_median * np.median(e_cpu)), (tag, "median", np.median(e_gpu), np.median(e_cpu))
-    assert p90g <= max(1e-5, f_p90 * p90c), (tag, "90th percentile", p90g, p90c)
-    assert np.median(direct) <= max(1e-5, f_direct * np.median(e_cpu)), (tag, "gpu-vs-cpu32 median", np.median(direct), np.median(e_cpu))
+          f"  grads vs fp64 over {len(keys)} tensors: gpu worst {e_gpu.max():.2e} ({keys[worst]}) median {np.median(e_gpu):.2e} p90 {p90g:.2e} | "
+          f"cpu32 all threads worst {e_cpuN.max():.2e} median {np.median(e_cpuN):.2e} p90 {np.percentile(e_cpuN, 90):.2e} | "
+          f"cpu32 one thread worst {e_cpu1.max():.2e} median {np.median(e_cpu1):.2e} p90 {np.percentile(e_cpu1, 90):.2e} | "
+          f"gpu-vs-cpu32 worst {direct.max():.2e} median {np.median(direct):.2e}\n"
+          f"  ratios gpu / yardstick: worst {e_gpu.max() / y_worst:.2f} median {np.median(e_gpu) / y_median:.2f} p90 {p90g / y_p90:.2f} "
+          f"direct-median {np.median(direct) / y_median:.2f}   (limits {F_WORST} / {F_MEDIAN} / {F_P90} / {F_DIRECT})")
+    assert e_gpu.max() <= max(1e-5, F_WORST * y_worst), (tag, "worst tensor", keys[worst], e_gpu.max(), y_worst)
+    assert np.median(e_gpu) <= max(1e-5, F_MEDIAN * y_median), (tag, "median", np.median(e_gpu), y_median)
+    assert p90g <= max(1e-5, F_P90 * y_p90), (tag, "90th percentile", p90g, y_p90)
+    assert np.median(direct) <= max(1e-5, F_DIRECT * y_median), (tag, "gpu-vs-cpu32 median", np.median(direct), y_median)
 
 
 @pytest.fixture(scope="module")
@@ -172,7 +193,7 @@ def test_airfoil_depth7_reference_default(eng):
     w, mesh = strip_mesh(327, 16, 7)
     r = run_config(eng, "airfoil", 4, "dense", mesh=mesh, cfg=w)
     assert len(r["levels"]) == 8 and r["levels"][0][0] == 5232 and r["levels"][-1][0] >= 2
-    # median factor 2.0 stays: the ratio is a property of WHICH near-zero ReLU inputs flip in the two fp32 runs, and the oracle's
-    # run depends on the host (CPU thread count -> summation order): measured 1.63 in round 4 (5.7e-5 vs 3.5e-5) and 0.22 in
-    # round 5 (2.4e-5 vs 1.07e-4) on two boxes of the pool, same GPU arithmetic for this configuration's dominant tensors
-    check(r, "airfoil-sized strip B=4 L=7 (reference default depth)", f_median=2.0)
+    # (rounds 4-5 allowed 2.0 for the median here: the ratio against ONE oracle run measured 1.63 on one box and 0.22 on another --
+    # the oracle's own summation order moves with the host's thread count.  Round 6: the yardstick is the larger of two oracle
+    # runs, one thread and all threads, and the factors are the same 1.5 as everywhere.)
+    check(r, "airfoil-sized strip B=4 L=7 (reference default depth)")

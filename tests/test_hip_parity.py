@@ -251,6 +251,61 @@ def test_bound_edge_weights_transitions_bit_identical(eng, graphs, name):
     assert torch.equal(y2.cpu(), want)
 
 
+def test_bound_edge_weights_lifetime_and_refresh(eng, graphs):
+    """the binding is by ADDRESS.  (1) bsms_plan_bound_edge_weights reports what a plan is bound to; (2) the
+    Python wrapper (ops._bind_edge_weights) keeps exactly the BOUND tensor alive -- a bind call the library declined (the plan is
+    bound elsewhere) must not replace it, or the allocator could recycle the bound address for other weights; (3) a rebuilt
+    chain with the SAME content gets the bound tensor back and stays on the compact lists; (4) binding the bound pointer again
+    is a no-op, also after an in-place change -- bind NULL, then bind again to refresh (include/bsms_hip.h)."""
+    from bsms_gnn_amd import _abi
+    from bsms_gnn_amd.ops import _bind_edge_weights, _stream
+    es, ids = graphs.levels("del300")
+    n0, nk = graphs.np("del300/pos").shape[0], ids[0].numel()
+    L = _abi.lib()
+    plan = eng.LevelPlan(dev(es[0]), n0, ids=dev(ids[0]))
+    assert not L.bsms_plan_bound_edge_weights(plan.handle)
+    ew = dev(ro.cal_ew(torch.ones(n0, 1), es[0])[0])
+    assert _bind_edge_weights(plan, ew) is ew and L.bsms_plan_bound_edge_weights(plan.handle) == ew.data_ptr() and plan._ew_bound is ew
+    other = ew * 0.5                                        # different content: declined, the held tensor stays
+    assert _bind_edge_weights(plan, other) is other
+    assert L.bsms_plan_bound_edge_weights(plan.handle) == ew.data_ptr() and plan._ew_bound is ew
+    same = ew.clone()                                       # a rebuilt chain: new tensor, same content -> the bound one is handed back
+    assert _bind_edge_weights(plan, same) is ew and plan._ew_bound is ew
+
+    def restrict(w):
+        x = torch.arange(n0 * 4, device="cuda", dtype=torch.float32).reshape(1, n0, 4).sin()
+        y = torch.empty(1, nk, 4, device="cuda")
+        _abi.check(L.bsms_edge_conv(plan.handle, x.data_ptr(), 1, 4, w.data_ptr(), 1, 1, y.data_ptr(), _stream()), "edge_conv")
+        return y
+
+    y0 = restrict(ew)
+    ew.mul_(2.0)                                            # in-place change of the bound tensor
+    _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, ew.data_ptr(), _stream()), "rebind same pointer")
+    assert torch.equal(restrict(ew), y0)                    # documented: a no-op, the gathered copies are the old values
+    _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, None, _stream()), "unbind")
+    assert not L.bsms_plan_bound_edge_weights(plan.handle)
+    y_slow = restrict(ew)                                   # unbound: index chasing, the new values
+    _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, ew.data_ptr(), _stream()), "bind")
+    y_fast = restrict(ew)
+    assert torch.equal(y_fast, y_slow) and not torch.equal(y_fast, y0)
+    want = ro.edge_conv(torch.arange(n0 * 4, dtype=torch.float32).reshape(1, n0, 4).sin(), es[0], ew.cpu())[:, ids[0]]
+    assert torch.equal(y_fast.cpu(), want)
+
+
+def test_inference_work_size_excludes_backward_sets(eng, graphs):
+    """bsms_bsgmp_infer_work_bytes: the forward's part of the scratch layout only; the rollout path sizes its
+    session buffer with it (covered end to end by the rollout tests)."""
+    from bsms_gnn_amd import _abi
+    es, ids = graphs.levels("del300")
+    sizes = [graphs.np("del300/pos").shape[0]] + [int(i.numel()) for i in ids]
+    plans = [eng.LevelPlan(dev(es[l]), sizes[l], ids=dev(ids[l]) if l < len(ids) else None) for l in range(len(es))]
+    pl, keep = _abi.ptr_array([q.handle.value for q in plans])
+    L = _abi.lib()
+    full = L.bsms_bsgmp_work_bytes(pl, len(plans) - 1, 8, 128, 2, 3)
+    infer = L.bsms_bsgmp_infer_work_bytes(pl, len(plans) - 1, 8, 128, 2, 3)
+    assert 0 < infer < full and infer * 2 < full, (infer, full)
+
+
 def test_cal_ew_degree_quirk(eng):
     """degree() has length max(g[0])+1: a trailing node without out-edges breaks w/deg."""
     g = torch.tensor([[0, 1], [1, 2]])  # node 2 never sends
