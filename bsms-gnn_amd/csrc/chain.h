@@ -89,6 +89,10 @@ struct ChainFwdArgs {
   const float4* wp[kMaxStages];  // packs (the Linear's bias travels in the pack header, see PackDesc)
   const float4* wp0b;  // IN_ROWS2: pack for x2 in stage 0 (same scale as wp[0]: PackDesc::mate; the stage's bias rides in THIS pack)
   float* store[kMaxStages];  // post-ReLU activation of stage l, act_floats(R, D) floats: values + sign bits (nullable)
+  int pieces;                // IN_EDGE, D = 128 (round 6): store_in / store[] receive the fp16 x 2 PIECES of the rows instead of fp32 values
+                             // (row r: K block c at byte 512 r + 128 c = 64 bytes of h pieces, 64 of l pieces, in the lane order of the B
+                             // operand; same size, sign bits in the same place) and store_exp[] the rows' scale exponents (RowScale::E)
+  int* store_exp[kMaxStages];  // pieces: [0] for store_in, [l + 1] for store[l]; pad_rows(R) ints each
   // ---- output
   float* y;           // OUT_LN / OUT_PLAIN: [R,D]; OUT_SMALL: [R,C]
   float* y2;          // OUT_PLAIN2: second head [R,D]

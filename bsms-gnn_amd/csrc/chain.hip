@@ -1078,14 +1078,24 @@ struct Pieces { unsigned h[4], l[4]; };
 __device__ __forceinline__ u32x4 vec4(const unsigned (&d)[4]) { return u32x4{d[0], d[1], d[2], d[3]}; }
 struct StepState { int got[4]; };
 
-template <int NB, int RB, bool SAVE, bool MASK>
+// SAVE: 0 nothing is stored; 1 the activation as fp32 rows (128-byte streaming pairs) + sign bits; 2 (round 6, the fused fp32 edge
+// backward, efuse32.hip) the fp16 x 2 PIECES this stage multiplies anyway -- K block c of a row as 64 bytes of h pieces followed
+// by 64 bytes of l pieces at byte 512 row + 128 c of the tensor (the four lane groups of a row write 16 bytes each), + sign bits;
+// the row's scale exponent goes to a side array (stage_rb).  Same bytes as the fp32 row, no DPP exchange, two steps instead of four.
+template <int NB, int RB, int SAVE, bool MASK>
 __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][NB], Pieces (&pc)[RB][2], StepState (&st)[RB],
                                           const RowScale (&rs)[RB], unsigned (&mword)[RB][mask_words<NB>()], float* store_base,
                                           unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB], int lane) {
-  constexpr int W = mask_words<NB>(), NP = SAVE ? 4 : 0, PER = NP + 8;
+  constexpr int W = mask_words<NB>(), NP = SAVE == 2 ? 2 : (SAVE ? 4 : 0), PER = NP + 8;
   const int rb = s / PER, q = s % PER;
   if (rb >= RB) return;
   const bool last = c + 1 == Ring<NB>::NCH;
+  if (SAVE == 2 && q < NP) {   // ---- P steps, pieces: K block c is being multiplied right now (pc[.][c & 1]); S steps write the other slot
+    const Pieces& pcs = pc[rb][c & 1];
+    char* b = reinterpret_cast<char*>(store_base) + 128 * c + 64 * q;   // uniform
+    *reinterpret_cast<u32x4*>(b + off[rb].a) = q == 0 ? vec4(pcs.h) : vec4(pcs.l);   // plain stores: 64-byte pieces per row (streaming stores of that size run at 3.1 TB/s, plain ones are pattern-insensitive; census/store_bw.hip)
+    return;
+  }
   if (q < NP) {   // ---- P steps
     const f32x4& own = act[rb][2 * c + 1];
     const bool hi = (lane & 8) != 0;
@@ -1139,15 +1149,16 @@ __device__ __forceinline__ void valu_step(int s, int c, const f32x4 (&act)[RB][N
 // call: same row scales, pack of the same weight scale); FIN = 0 leave raw sums, 1 un-scale, 2 un-scale + bias.
 // `rs_ext` (nullable): row scales decided by the caller (a Linear over two concatenated sources); else the row maxima of
 // `act` are taken here and noted in the running bounds (`brow`, stage index `stage`).
-template <int NB, int RB, bool SAVE, bool MASK, bool ZERO, int FIN, bool LONE = false>
+template <int NB, int RB, int SAVE, bool MASK, bool ZERO, int FIN, bool LONE = false>
 __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act)[RB][NB], float4* lds, Slot& slot, int lane,
                                          float* store_base, unsigned* bits_base, const PairOff (&off)[RB], const unsigned (&moff)[RB],
                                          unsigned* brow, int stage, const RowScale* rs_ext = nullptr,
-                                         unsigned long long* waited = nullptr) {   // experiments: cycles at the chunk barriers
+                                         unsigned long long* waited = nullptr,   // experiments: cycles at the chunk barriers
+                                         int* exps_tile = nullptr) {            // SAVE == 2: scale exponents of this tile's rows
   using Rg = Ring<NB>;
   constexpr int W = mask_words<NB>();
   constexpr int NSLOT = (NB / 2) * 3 * RB;            // MFMA pairs per chunk
-  constexpr int NSTEP = RB * ((SAVE ? 4 : 0) + 8);    // VALU steps per chunk
+  constexpr int NSTEP = RB * ((SAVE == 2 ? 2 : (SAVE ? 4 : 0)) + 8);    // VALU steps per chunk
   static_assert(NSTEP <= NSLOT, "at most one step per MFMA pair");
   Pieces pc[RB][2];                                   // pieces of K blocks c (slot c & 1) and c + 1
   StepState st[RB];
@@ -1168,6 +1179,7 @@ __device__ __forceinline__ void stage_rb(f32x4 (&acc)[RB][NB], const f32x4 (&act
     for (int v = 0; v < 4; ++v) { pc[rb][0].h[v] = h[v]; pc[rb][0].l[v] = l[v]; }
 #pragma unroll
     for (int w = 0; w < W; ++w) mword[rb][w] = 0;
+    if (SAVE == 2 && (lane >> 4) == 0) exps_tile[moff[rb] / (16 * W)] = rs[rb].E;   // moff = (row in tile * 4 W + group * W) * 4 bytes
   }
   int fw = 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -1308,7 +1320,7 @@ struct EdgeTile {
 };
 
 // LONE: the instantiation for launches of at most one workgroup per CU (stage_rb<.., LONE>; 256-register budget)
-template <int NB, int RB, bool SAVE, bool LONE = false>
+template <int NB, int RB, int SAVE, bool LONE = false>
 __global__ __launch_bounds__(kChainMaxThreads) __attribute__((amdgpu_waves_per_eu(LONE ? 2 : EdgeTile<NB, RB>::waves_per_eu)))
 void k_edge_fwd(ChainFwdArgs a) {
   constexpr int D = NB * 16;
@@ -1358,6 +1370,7 @@ void k_edge_fwd(ChainFwdArgs a) {
     for (int rb = 0; rb < RB; ++rb) {
       row[rb] = int64_t(tile) * tile_rows + wave * (16 * RB) + rb * 16 + (lane & 15);
       off[rb] = pair_offsets<NB>(wave * (16 * RB) + rb * 16 + (lane & 15), lane);                         // within the tile
+      if (SAVE == 2) off[rb].a = unsigned((wave * (16 * RB) + rb * 16 + (lane & 15)) * (4 * D) + 16 * lg);    // pieces: this lane's 16 bytes of a K block's h run (valu_step)
       moff[rb] = unsigned(((wave * (16 * RB) + rb * 16 + (lane & 15)) * (4 * mask_words<NB>()) + lg * mask_words<NB>()) * 4);
       const int i = ni[rb], j = nj[rb], b = nbat[rb];
       load_rows<NB>(act[rb], a.Ps + (int64_t(b) * a.N + i) * D, lg);
@@ -1408,20 +1421,23 @@ void k_edge_fwd(ChainFwdArgs a) {
     }
     // ---- MFMA stages; the activation entering a stage is stored (values + sign bits) from inside that stage
     float* pending = a.store_in;   // uniform; non-null when SAVE (launcher)
+    int* pending_exp = SAVE == 2 ? a.store_exp[0] : nullptr;   // uniform; non-null when SAVE == 2 (launcher)
     stamp();
     for (int l = 0; l < a.nstage; ++l) {
       float* st_tile = SAVE ? pending + int64_t(tile) * (tile_rows * D) : nullptr;   // uniform
       unsigned* bits_tile = SAVE ? reinterpret_cast<unsigned*>(pending + pad_rows(a.R) * D) + int64_t(tile) * (tile_rows * 4 * mask_words<NB>()) : nullptr;
+      int* exps_tile = SAVE == 2 ? pending_exp + int64_t(tile) * tile_rows : nullptr;
 #ifdef BSMS_EXPERIMENTS
-      stage_rb<NB, RB, SAVE, true, true, 2, LONE>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l, nullptr, a.timing ? &waited : nullptr);
+      stage_rb<NB, RB, SAVE, true, true, 2, LONE>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l, nullptr, a.timing ? &waited : nullptr, exps_tile);
 #else
-      stage_rb<NB, RB, SAVE, true, true, 2, LONE>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l);   // acc = bias + W act
+      stage_rb<NB, RB, SAVE, true, true, 2, LONE>(acc, act, ring, slot, lane, st_tile, bits_tile, off, moff, brow, l, nullptr, nullptr, exps_tile);   // acc = bias + W act
 #endif
       stamp();
       if (l + 1 < a.nstage) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) relu_into<NB>(act[rb], acc[rb]);
         pending = a.store[l];
+        if (SAVE == 2) pending_exp = a.store_exp[l + 1];
       }
     }
     // ---- LayerNorm(elementwise_affine=False), eps 1e-5  (ops/basic.py:18)
@@ -1526,7 +1542,7 @@ void k_edge_bwd(ChainBwdArgs a) {
 #else
       float* const gtile = pending + int64_t(tile) * (tile_rows * D);
 #endif
-      stage_rb<NB, RB, true, false, true, 1, LONE>(acc, g, ring, slot, lane, gtile, nullptr, off, moff, brow, k);
+      stage_rb<NB, RB, 1, false, true, 1, LONE>(acc, g, ring, slot, lane, gtile, nullptr, off, moff, brow, k);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -1666,7 +1682,7 @@ void pick_stream(int64_t ntiles, int cw, int nload_default, int& nload, int& nri
   while (nring > 3 && (nring - 2) * mine > 63) --nring;
 }
 
-template <int NB, int RB, bool SAVE>
+template <int NB, int RB, int SAVE>
 int launch_edge_fwd_t(ChainFwdArgs& a, hipStream_t s) {
   static DynLdsAttr attr_dev;
   const hipError_t attr = attr_dev.ensure(reinterpret_cast<const void*>(&k_edge_fwd<NB, RB, SAVE>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
@@ -1704,8 +1720,17 @@ bool launch_edge_fwd(ChainFwdArgs& a, hipStream_t s, int& rc) {
   const int64_t cus = device_cus(), rows1 = 16 * edge_compute_waves<NB>();   // rows of a tile with one row block per wave
   bool big = RBIG == 2 && a.R >= cus * rows1 && ceil_div(a.R, rows1) <= cus * EdgeTile<NB, 1>::resident;
   if (edge_rb_mode() > 0) big = RBIG == 2 && edge_rb_mode() == 2;
-  if (big) rc = save ? launch_edge_fwd_t<NB, RBIG, true>(a, s) : launch_edge_fwd_t<NB, RBIG, false>(a, s);
-  else rc = save ? launch_edge_fwd_t<NB, 1, true>(a, s) : launch_edge_fwd_t<NB, 1, false>(a, s);
+  if constexpr (NB == 8) {
+    if (save && a.pieces) {   // the activations leave as the fp16 x 2 pieces of their own stage (valu_step SAVE == 2): efuse32.hip reads them back
+      for (int l = 0; l < a.nstage; ++l)
+        if (!a.store_exp[l]) return false;
+      rc = big ? launch_edge_fwd_t<NB, RBIG, 2>(a, s) : launch_edge_fwd_t<NB, 1, 2>(a, s);
+      return true;
+    }
+  }
+  if (a.pieces) return false;
+  if (big) rc = save ? launch_edge_fwd_t<NB, RBIG, 1>(a, s) : launch_edge_fwd_t<NB, RBIG, 0>(a, s);
+  else rc = save ? launch_edge_fwd_t<NB, 1, 1>(a, s) : launch_edge_fwd_t<NB, 1, 0>(a, s);
   return true;
 }
 

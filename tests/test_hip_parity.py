@@ -272,8 +272,10 @@ def test_bound_edge_weights_lifetime_and_refresh(eng, graphs):
     same = ew.clone()                                       # a rebuilt chain: new tensor, same content -> the bound one is handed back
     assert _bind_edge_weights(plan, same) is ew and plan._ew_bound is ew
 
+    x_cpu = torch.arange(n0 * 4, dtype=torch.float32).reshape(1, n0, 4).sin()   # ONE input for both sides (sin differs in the last bit between devices)
+    x = x_cpu.cuda()
+
     def restrict(w):
-        x = torch.arange(n0 * 4, device="cuda", dtype=torch.float32).reshape(1, n0, 4).sin()
         y = torch.empty(1, nk, 4, device="cuda")
         _abi.check(L.bsms_edge_conv(plan.handle, x.data_ptr(), 1, 4, w.data_ptr(), 1, 1, y.data_ptr(), _stream()), "edge_conv")
         return y
@@ -288,7 +290,7 @@ def test_bound_edge_weights_lifetime_and_refresh(eng, graphs):
     _abi.check(L.bsms_plan_bind_edge_weights(plan.handle, ew.data_ptr(), _stream()), "bind")
     y_fast = restrict(ew)
     assert torch.equal(y_fast, y_slow) and not torch.equal(y_fast, y0)
-    want = ro.edge_conv(torch.arange(n0 * 4, dtype=torch.float32).reshape(1, n0, 4).sin(), es[0], ew.cpu())[:, ids[0]]
+    want = ro.edge_conv(x_cpu, es[0], ew.cpu())[:, ids[0]]
     assert torch.equal(y_fast.cpu(), want)
 
 
