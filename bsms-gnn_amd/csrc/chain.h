@@ -247,17 +247,16 @@ struct EdgeFusedBwdArgs {
   int ntiles;                 // filled by the launcher
   unsigned long long* timing; // experiments only: phase stamps (null in production)
 };
-// efuse32.hip: the same in fp32 (BSMS_F32): weights streamed through the LDS ring in the order [W_1, W_2, W_3^T, W_2^T, W_1^T] per tile,
-// running block exponents for the dW operands; partials in the layout of efuse.hip (launch_edge_fused_reduce sums them)
+// csrc/experiments/efuse32.hip (EXPERIMENT builds only): fp32 (BSMS_F32), round 6: LayerNorm backward + dgrad chain + dW / db of Linears 1..3 on chip WITHOUT forward recompute --
+// the forward saved a_0..a_2 as fp16 x 2 pieces (ChainFwdArgs::pieces), the backward brings their tiles HBM -> LDS by LDS-DMA; the
+// transposed packs stream through the LDS ring; partials in the layout of efuse.hip (launch_edge_fused_reduce sums them)
 struct EdgeFused32Args {
   int64_t R;                  // B * E edge rows (plan order)
   int32_t E, N;
-  const int32_t *src, *dst;   // plan-order endpoints
-  const float *Ps, *Pd;       // the forward's node projections [B*N, D]
-  const float* fiber;         // [R, 4]
-  const float* wft;           // fiber weights^T [p+1][D]
-  int p;
-  const float4* wseq[5];      // packs in execution order: FRAG of Linears 1, 2; FRAG_T of Linears 3, 2, 1 (biases ride in the FRAG packs)
+  const int32_t* dst;         // plan-order targets
+  const float* act[3];        // a_2, a_1, a_0 (execution order) as saved by k_edge_fwd SAVE == 2: pieces + sign bits (act_floats layout)
+  const int* aexp[3];         // their rows' scale exponents
+  const float4* wseq[3];      // FRAG_T packs of Linears 3, 2, 1
   const float* dy;            // [B*N, D] gradient of the aggregate (gathered by target)
   const float* y;             // [R, D] messages
   const float* rstd;          // [R]

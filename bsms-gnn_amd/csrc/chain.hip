@@ -1720,6 +1720,7 @@ bool launch_edge_fwd(ChainFwdArgs& a, hipStream_t s, int& rc) {
   const int64_t cus = device_cus(), rows1 = 16 * edge_compute_waves<NB>();   // rows of a tile with one row block per wave
   bool big = RBIG == 2 && a.R >= cus * rows1 && ceil_div(a.R, rows1) <= cus * EdgeTile<NB, 1>::resident;
   if (edge_rb_mode() > 0) big = RBIG == 2 && edge_rb_mode() == 2;
+#ifdef BSMS_EXPERIMENTS   // (the only reader of the pieces, experiments/efuse32.hip, is not in the product library: no instantiation there)
   if constexpr (NB == 8) {
     if (save && a.pieces) {   // the activations leave as the fp16 x 2 pieces of their own stage (valu_step SAVE == 2): efuse32.hip reads them back
       for (int l = 0; l < a.nstage; ++l)
@@ -1728,6 +1729,7 @@ bool launch_edge_fwd(ChainFwdArgs& a, hipStream_t s, int& rc) {
       return true;
     }
   }
+#endif
   if (a.pieces) return false;
   if (big) rc = save ? launch_edge_fwd_t<NB, RBIG, 1>(a, s) : launch_edge_fwd_t<NB, RBIG, 0>(a, s);
   else rc = save ? launch_edge_fwd_t<NB, 1, 1>(a, s) : launch_edge_fwd_t<NB, 1, 0>(a, s);
@@ -1795,6 +1797,7 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
     int rc = BSMS_OK;
     if (launch_edge_fwd<NB>(a, s, rc)) return rc;
   }
+  BSMS_REQUIRE(!a.pieces, BSMS_E_UNSUPPORTED, "chain_fwd: only the pipelined edge kernel at D = 128 saves fp16 x 2 pieces (R = %lld, stages %d)", (long long)a.R, a.nstage);
   if constexpr (NB == 8 && (IN == IN_ROWS || IN == IN_ROWS2 || IN == IN_SMALL)) {   // small launches: the feature-split kernel
     static const int fs_rows = knob("BSMS_FS_ROWS", kFsMaxRows);
     if (!a.bf16 && a.R <= fs_rows && a.nseq >= 1 && a.nseq <= kMaxStages + 1) {

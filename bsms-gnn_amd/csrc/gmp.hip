@@ -59,7 +59,8 @@ void add_pack(PackTable& t, const float* W, int ld, int row0, int col0, int N, i
 // ================================================================================== GMP layout
 struct GmpSaved {
   float *e_act[kMaxStages], *e_y, *e_rstd, *aggr, *e_fiber;
-  float *e_Ps, *e_Pd;   // fused edge backward (efuse.hip): the two node projections are kept for the backward's recompute
+  float *e_Ps, *e_Pd;   // fused edge backward of the bf16 precisions (efuse.hip): the two node projections are kept for the backward's recompute
+  int* e_aexp[kMaxStages];   // fused fp32 edge backward (efuse32.hip): scale exponents of the rows of e_act[l], which then holds fp16 x 2 pieces
   float *n_act[kMaxStages], *n_yln, *n_rstd;
   // packs (fragment order)
   float *e_wi, *e_wj, *e_wft, *e_w[kMaxStages], *e_wt[kMaxStages], *e_wit, *e_wjt;
@@ -77,16 +78,19 @@ struct GmpSaved {
 // they can be filled ahead of the call and survive the scratch reuse of other blocks.
 // `bf`: bf16 precision -- the edge activations and the messages are bf16 (half the floats; the sign bits keep their size);
 // `bfn` (BSMS_BF16_NODES): the node MLP's saved activations likewise
-// `fused` (use_edge_fused): the edge backward recomputes its activations (efuse.hip): no e_act tensors, the projections instead
+// `fused` (use_edge_fused): bf16 precisions -- the edge backward recomputes its activations (efuse.hip): no e_act tensors, the projections
+// instead; fp32 -- e_act[l] hold the fp16 x 2 pieces of the rows (chain.hip: k_edge_fwd SAVE == 2) and e_aexp[l] their scale exponents (efuse32.hip)
 GmpSaved carve_gmp_saved(void* base, int64_t B, int64_t N, int64_t E, int64_t D, int H, bool training = true,
                          void* packs_base = nullptr, bool bf = false, bool bfn = false, bool fused = false) {
   Carver c(base);
   GmpSaved s{};
   const size_t re = size_t(B) * E, rn = size_t(B) * N, dd = pack_floats(D);
   const size_t edge_act = bf ? pad_rows(re) * (size_t(D) / 2 + mask_words_per_row(D)) : act_floats(re, D);
-  if (training && !fused)
+  if (training && (!fused || !bf))
     for (int l = 0; l < H; ++l) s.e_act[l] = c.take(edge_act);
-  if (training && fused) { s.e_Ps = c.take(rn * D); s.e_Pd = c.take(rn * D); }
+  if (training && fused && !bf)   // fp32 fused backward: the activations are kept as the pieces of their own stage + one exponent per row
+    for (int l = 0; l < H; ++l) s.e_aexp[l] = reinterpret_cast<int*>(c.take(pad_rows(re)));
+  if (training && fused && bf) { s.e_Ps = c.take(rn * D); s.e_Pd = c.take(rn * D); }
   s.e_y = c.take(bf ? re * D / 2 : re * D);
   if (training) s.e_rstd = c.take(re);
   if (training) s.e_fiber = c.take(re * 8);   // [B*E, fiber_ld(p)]: sized for the widest pitch (p is not part of the size query)
@@ -166,16 +170,18 @@ static const int g_edge_fwd_res = env_fwd_res();   // A/B against the generic ri
 #else
 constexpr int g_edge_fwd_res = 1;
 #endif
-// The fp32 port (efuse32.hip): under development -- experiment builds switch it on with BSMS_EDGE_FUSED_F32=1, the production build
-// keeps the unfused fp32 dataflow until the same-box A/B says otherwise (profiles/r05_efuse32_ab.txt).
+// The fp32 fused edge backward (csrc/experiments/efuse32.hip, round 6: dgrad + dW on chip without forward recompute) is NOT in the
+// product library: same-box 176-180 against 186.5 steps/s for the unfused dataflow (profiles/r06_efuse32_notes.txt).  Experiment
+// builds (profiles/build_efv.sh) link it and switch it on with BSMS_EDGE_FUSED_F32=1.
 #ifdef BSMS_EXPERIMENTS
 static int env_fused32() { const char* e = getenv("BSMS_EDGE_FUSED_F32"); return e ? atoi(e) : 0; }
 static const int g_edge_fused32 = env_fused32();
+static bool fused32_on(int64_t D, int H, int precision) { return g_edge_fused32 && edge_fused32_supported(D, H, 1, precision); }
 #else
-constexpr int g_edge_fused32 = 0;
+static bool fused32_on(int64_t, int, int) { return false; }
 #endif
 bool use_edge_fused(int64_t D, int H, int precision) {
-  return precision == BSMS_F32 ? (g_edge_fused32 && edge_fused32_supported(D, H, 1, precision)) : (g_edge_fused && edge_fused_supported(D, H, 1, precision));
+  return precision == BSMS_F32 ? fused32_on(D, H, precision) : (g_edge_fused && edge_fused_supported(D, H, 1, precision));
 }
 
 bool edge_fused_possible(int64_t D, int H) { return use_edge_fused(D, H, BSMS_F32) || use_edge_fused(D, H, BSMS_BF16) || use_edge_fused(D, H, BSMS_BF16_NODES); }
@@ -296,7 +302,9 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
   GmpWork wk = carve_gmp_work(work, B, N, E, D, H);
   GmpSaved sv = locate_saved(saved, wk, B, N, E, D, H, packs_base, bf, bfn);
   if (do_prepack && (rc = prepack_block(sv, D, p, H, training, params, s, bf, bfn))) return rc;
-  const bool fused = training && use_edge_fused(D, H, precision);   // the backward recomputes the edge activations (efuse.hip)
+  const bool fused_any = training && use_edge_fused(D, H, precision);
+  const bool fused = fused_any && bf;       // the backward recomputes the edge activations (efuse.hip): the projections are kept instead
+  const bool fused32 = fused_any && !bf;    // the activations are saved as fp16 x 2 pieces for efuse32.hip
   float* const Ps = fused ? sv.e_Ps : wk.Ps;
   float* const Pd = fused ? sv.e_Pd : wk.Pd;
 
@@ -329,6 +337,10 @@ int bsms::gmp_fwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     for (int st = 0; st < H; ++st) {
       a.wp[st] = reinterpret_cast<const float4*>(sv.e_w[st + 1]);
       a.store[st] = (training && !fused && st < H - 1) ? sv.e_act[st + 1] : nullptr;
+    }
+    if (fused32) {
+      a.pieces = 1;
+      for (int st = 0; st < H; ++st) a.store_exp[st] = sv.e_aexp[st];
     }
     a.y = sv.e_y; a.rstd = sv.e_rstd;
     if (training && !bf) for (int st = 0; st < H; ++st) a.amax[st] = sv.bound + size_t(st) * kBoundWidth;
@@ -436,17 +448,22 @@ int bsms::gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, 
     if ((rc = launch_chain_bwd((int)D, G_ROWS_LN, F_HEADS2, a, s))) return rc;
   }
   // edge MLP backward (gradient of the aggregation = gather by target)
-  if (fused && !bf) {   // the same in fp32 (efuse32.hip): packs streamed through the LDS ring, running block exponents for the dW operands
+#ifdef BSMS_EXPERIMENTS
+  if (fused && !bf) {   // fp32 (experiments/efuse32.hip): dgrad chain + dW on chip, A tiles from the saved pieces by LDS-DMA, running block exponents
     EdgeFused32Args a{};
-    a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
-    a.Ps = sv.e_Ps; a.Pd = sv.e_Pd; a.fiber = sv.e_fiber; a.wft = sv.e_wft; a.p = (int)p;
-    a.wseq[0] = reinterpret_cast<const float4*>(sv.e_w[1]); a.wseq[1] = reinterpret_cast<const float4*>(sv.e_w[2]);
-    for (int l = 3; l >= 1; --l) a.wseq[2 + (3 - l)] = reinterpret_cast<const float4*>(sv.e_wt[l]);
+    a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.dst = plan->dst;
+    for (int k = 0; k < 3; ++k) {   // execution order: Linear 3, 2, 1
+      a.wseq[k] = reinterpret_cast<const float4*>(sv.e_wt[3 - k]);
+      a.act[k] = sv.e_act[2 - k];
+      a.aexp[k] = sv.e_aexp[2 - k];
+    }
     a.dy = wk.daggr; a.y = sv.e_y; a.rstd = sv.e_rstd; a.g0 = wk.gE[0];
     a.part = wk.ef_part;
     a.timing = g_timing;
     if ((rc = launch_edge_fused32_bwd(a, &ef_nwg, s))) return rc;
-  } else if (fused) {   // recompute + LayerNorm backward + dgrad + the weight gradients of Linears 1..H on chip (efuse.hip)
+  } else
+#endif
+  if (fused) {   // recompute + LayerNorm backward + dgrad + the weight gradients of Linears 1..H on chip (efuse.hip)
     EdgeFusedBwdArgs a{};
     a.R = B * E; a.E = (int32_t)E; a.N = (int32_t)N; a.src = plan->src; a.dst = plan->dst;
     a.Ps = sv.e_Ps; a.Pd = sv.e_Pd; a.fiber = sv.e_fiber; a.wft = sv.e_wft; a.p = (int)p;

@@ -1,4 +1,4 @@
-"""Phase stamps (s_memtime) of the fp32 fused edge backward k_edge_fused32_bwd (efuse32.hip): chain wave 0 of every workgroup;
+"""Phase stamps (s_memtime) of the fp32 fused edge backward k_edge_fused32_bwd (efuse32.hip, round 6: no recompute): chain wave 0 of every workgroup;
 experiment build only, BSMS_EDGE_FUSED_F32=1.   python profiles/ef32_timeline.py [level]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,9 +8,8 @@ from bench import build_workload
 wl = build_workload("airfoil", 8, "cuda")
 raw = ctypes.CDLL(eng._abi.LIB_PATH)
 raw.bsms_debug_set_timing.argtypes = [ctypes.c_void_p]
-names = ["locate + Ps / Pd / fiber gathers + a_0", "fwd Linear 1 (4 chunks) + relu", "fwd Linear 2 + relu", "dy / y gathers + LayerNorm bwd + row max",
-         "publish maxima", "dgrad 3 (4 chunks) + mask", "hand-over 3 + row max + publish", "dgrad 2 + mask", "hand-over 2 + row max + publish",
-         "dgrad 1 + mask", "hand-over 1", "g0 stores"]
+names = ["previous g0 stores + locate + loads issued", "loads arrive + LayerNorm bwd", "row max + publish + barrier X + hand-over 3 + db", "dgrad 3 (4 chunk periods)", "mask",
+         "row max + publish + X + hand-over 2 + db", "dgrad 2", "mask", "row max + publish + X + hand-over 1 + db", "dgrad 1", "mask", "g0 copy"]
 for lvl in [int(a) for a in sys.argv[1:]] or [0, 3]:
     n0, e0 = wl["levels"][lvl]
     g0 = wl["m_gs"][lvl][0]
