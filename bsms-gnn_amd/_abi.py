@@ -26,6 +26,8 @@ SIGNATURES = {
     "bsms_plan_min_out_degree": (c_i64, [c_void_p]),
     "bsms_plan_max_source": (c_i64, [c_void_p]),
     "bsms_plan_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bsms_plan_export_ex": (c_i64, [c_void_p, c_int, c_void_p]),
+    "bsms_plan_concat": (c_int, [PP, c_int, c_void_p, c_void_p, c_void_p, c_void_p, PP]),
     "bsms_segment_sum_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "bsms_segment_sum_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
     "bsms_segment_sum_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]),

@@ -111,6 +111,32 @@ int gmp_bwd_core(const bsms_plan* plan, const float* x, const float* pos, const 
                  float* grad_x, float* const* grads, int defer_slot, hipStream_t stream, int precision = BSMS_F32);
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// bsms_plan_concat (plan.hip: host side; rowsum.hip: the kernel -- plan.hip is also compiled as plain C++ for the sanitizer build):
+// the index blocks of up to kCatParts plans copied into the blocks of their block-diagonal union, node / edge / pooled offsets added
+constexpr size_t kIdxAlign = 64;   // int32 elements (256 bytes) between the arrays of a plan's index block
+#ifdef __HIPCC__
+#define BSMS_HD __host__ __device__
+#else
+#define BSMS_HD
+#endif
+BSMS_HD inline size_t idx_pad(size_t n) { return (n + kIdxAlign - 1) / kIdxAlign * kIdxAlign; }
+constexpr int kCatParts = 16;
+struct CatPart {
+  const int32_t *blk, *pool;               // the part's two device blocks (pool: null when no part has one)
+  int32_t N, E, Nk, Ek, Ep;                // its sizes ...
+  int32_t n_off, e_off, k_off, ek_off, ep_off;   // ... and where it starts in the union
+};
+struct CatArgs {
+  CatPart part[kCatParts];
+  int nparts;
+  int32_t *out_blk, *out_pool;             // blocks of the union, laid out for (N, E, Nk, Ek, Ep) below
+  int32_t N, E, Nk, Ek, Ep;
+  int has_w;                               // copy the gathered edge weights k_w / p_w too (every part is bound)
+  int64_t* coo_out;                        // nullable: [2, E] int64 edge list of the union in the CALLER's edge order
+  int64_t* ids_out;                        // nullable: [Nk] int64 kept ids of the union
+};
+int launch_plan_concat(const CatArgs& a, hipStream_t s) __attribute__((weak));   // rowsum.hip (absent from the host-only sanitizer library)
+
 }  // namespace bsms
 
 // One mesh level in HBM.  All arrays int32, owned by the plan.

@@ -245,8 +245,6 @@ int upload_block(int32_t** dev, size_t* cap, const std::vector<int32_t>& host) {
   }
   return BSMS_OK;
 }
-constexpr size_t kIdxAlign = 64;   // int32 elements (256 bytes) between the arrays of a block
-inline size_t idx_pad(size_t n) { return (n + kIdxAlign - 1) / kIdxAlign * kIdxAlign; }
 }  // namespace
 
 extern "C" int bsms_plan_create(const int64_t* coo, int64_t E, int64_t N, bsms_plan_t** out) {
@@ -413,6 +411,137 @@ extern "C" int bsms_plan_set_pool(bsms_plan_t* p, const int64_t* ids, int64_t Nk
     std::vector<int32_t>().swap(p->host);
   }
   return BSMS_OK;
+}
+
+// The pointers of a plan into its two blocks, from its sizes (the layouts bsms_plan_create / bsms_plan_set_pool write)
+static void point_into_blocks(bsms_plan* p) {
+  const size_t nN = idx_pad(size_t(p->N) + 1), nE = idx_pad(size_t(p->E));
+  p->rowptr = p->block;
+  p->t_rowptr = p->rowptr + nN;
+  p->src = p->t_rowptr + nN;
+  p->dst = p->src + nE;
+  p->perm = p->dst + nE;
+  p->t_dst = p->perm + nE;
+  p->t_eid = p->t_dst + nE;
+  p->t_pos = p->t_eid + nE;
+  if (!p->pool_block) return;
+  const size_t nK = idx_pad(size_t(p->Nk)), nNinv = idx_pad(size_t(p->N)), nK1 = idx_pad(size_t(p->Nk) + 1),
+               nEk = idx_pad(size_t(p->Ek)), nEp = idx_pad(size_t(p->Ep));
+  p->ids = p->pool_block;
+  p->inv = p->pool_block + nK;
+  p->k_rowptr = p->inv + nNinv;
+  p->k_src = p->k_rowptr + nK1;
+  p->k_eid = p->k_src + nEk;
+  p->p_rowptr = p->k_eid + nEk;
+  p->p_src = p->p_rowptr + nN;
+  p->p_eid = p->p_src + nEp;
+  p->k_w = reinterpret_cast<float*>(p->p_eid + nEp);
+  p->p_w = p->k_w + nEk;
+}
+
+// Block-diagonal union of plans ON THE DEVICE (round 6).  The stable dst-sorted CSR, its transpose and
+// the compact transition lists of an offset-concatenated edge list ARE the concatenations of the parts' arrays with node / edge /
+// pooled-row offsets added (the parts' target ranges are disjoint and ordered), so a batch of different meshes -- the reference's
+// cylinder_flow path, datasets/base.py:319-351 + PyG Batch, models/model.py:194-200 -- needs no host CSR build and no upload:
+// one kernel per 16 parts.  Result == bsms_plan_create on the concatenated COO + bsms_plan_set_pool on the offset ids
+// (+ bsms_plan_bind_edge_weights when `ew_cat` is given), array for array (tests/test_hip_host_builder.py).
+extern "C" int bsms_plan_concat(const bsms_plan_t* const* parts, int nparts, const float* ew_cat, int64_t* coo_out, int64_t* ids_out,
+                                bsms_stream_t stream, bsms_plan_t** out) {
+  BSMS_REQUIRE(out != nullptr, BSMS_E_INVALID_ARG, "plan_concat: out is null");
+  *out = nullptr;
+  BSMS_REQUIRE(parts != nullptr && nparts >= 1, BSMS_E_INVALID_ARG, "plan_concat: no parts");
+  BSMS_REQUIRE(launch_plan_concat != nullptr, BSMS_E_UNSUPPORTED, "plan_concat: this build has no device code");
+  const int dev = current_device();
+  int64_t N = 0, E = 0, Nk = 0, Ek = 0, Ep = 0;
+  bool pooled = parts[0] && parts[0]->ids != nullptr, bound = ew_cat != nullptr;
+  for (int b = 0; b < nparts; ++b) {
+    const bsms_plan* q = parts[b];
+    BSMS_REQUIRE(q != nullptr && q->block != nullptr, BSMS_E_INVALID_ARG, "plan_concat: part %d is null", b);
+    BSMS_REQUIRE(q->device == dev, BSMS_E_INVALID_ARG, "plan_concat: part %d lives on device %d, the current device is %d", b, q->device, dev);
+    BSMS_REQUIRE((q->ids != nullptr) == pooled, BSMS_E_INVALID_ARG, "plan_concat: part %d %s a pool, part 0 %s", b,
+                 q->ids ? "has" : "has no", pooled ? "has one" : "has none");
+    BSMS_REQUIRE(!bound || q->w_bound != nullptr, BSMS_E_INVALID_ARG, "plan_concat: ew_cat given but part %d has no bound edge weights", b);
+    N += q->N; E += q->E; Nk += q->Nk; Ek += q->Ek; Ep += q->Ep;
+  }
+  BSMS_REQUIRE(!bound || pooled, BSMS_E_INVALID_ARG, "plan_concat: ew_cat given but the parts have no pools");
+  BSMS_REQUIRE(E < (int64_t(1) << 31) && N < (int64_t(1) << 31), BSMS_E_UNSUPPORTED, "plan_concat: indices must fit int32 (E=%lld N=%lld)",
+               (long long)E, (long long)N);
+  bsms_plan* p = new bsms_plan();
+  p->device = dev;
+  p->N = N; p->E = E;
+  p->min_out_degree = (N > 0 || E > 0) ? INT64_MAX : 0;
+  const size_t nN = idx_pad(size_t(N) + 1), nE = idx_pad(size_t(E));
+  const size_t words = 2 * nN + 6 * nE;
+  int rc = alloc_block(&p->block, std::max<size_t>(words, 1) * sizeof(int32_t), &p->block_cap);
+  if (rc) { bsms_plan_destroy(p); return rc; }
+  p->host_words = words;
+  if (pooled) {
+    p->Nk = Nk; p->Ek = Ek; p->Ep = Ep;
+    const size_t nK = idx_pad(size_t(Nk)), nNinv = idx_pad(size_t(N)), nK1 = idx_pad(size_t(Nk) + 1), nEk = idx_pad(size_t(Ek)), nEp = idx_pad(size_t(Ep));
+    const size_t pw = nK + nNinv + nK1 + 2 * nEk + nN + 2 * nEp + nEk + nEp;
+    if ((rc = alloc_block(&p->pool_block, std::max<size_t>(pw, 1) * sizeof(int32_t), &p->pool_cap))) { bsms_plan_destroy(p); return rc; }
+  }
+  point_into_blocks(p);
+  int64_t n_off = 0, e_off = 0, k_off = 0, ek_off = 0, ep_off = 0;
+  for (int b0 = 0; b0 < nparts; b0 += kCatParts) {
+    CatArgs a{};
+    a.nparts = std::min(kCatParts, nparts - b0);
+    a.out_blk = p->block; a.out_pool = p->pool_block;
+    a.N = (int32_t)N; a.E = (int32_t)E; a.Nk = (int32_t)Nk; a.Ek = (int32_t)Ek; a.Ep = (int32_t)Ep;
+    a.has_w = bound ? 1 : 0;
+    a.coo_out = coo_out; a.ids_out = pooled ? ids_out : nullptr;
+    for (int i = 0; i < a.nparts; ++i) {
+      const bsms_plan* q = parts[b0 + i];
+      CatPart& c = a.part[i];
+      c.blk = q->block; c.pool = q->pool_block;
+      c.N = (int32_t)q->N; c.E = (int32_t)q->E; c.Nk = (int32_t)q->Nk; c.Ek = (int32_t)q->Ek; c.Ep = (int32_t)q->Ep;
+      c.n_off = (int32_t)n_off; c.e_off = (int32_t)e_off; c.k_off = (int32_t)k_off; c.ek_off = (int32_t)ek_off; c.ep_off = (int32_t)ep_off;
+      if (q->N > 0 || q->E > 0) p->min_out_degree = std::min(p->min_out_degree, q->min_out_degree);
+      if (q->max_source >= 0) p->max_source = std::max(p->max_source, n_off + q->max_source);
+      p->max_in_degree = std::max(p->max_in_degree, q->max_in_degree);
+      p->max_out_degree = std::max(p->max_out_degree, q->max_out_degree);
+      n_off += q->N; e_off += q->E; k_off += q->Nk; ek_off += q->Ek; ep_off += q->Ep;
+    }
+    if ((rc = launch_plan_concat(a, as_stream(stream)))) { bsms_plan_destroy(p); return rc; }
+  }
+  if (p->min_out_degree == INT64_MAX) p->min_out_degree = 0;
+  if (bound) p->w_bound = ew_cat;
+  *out = p;
+  return BSMS_OK;
+}
+
+// test accessor: array `which` of a plan copied to the host as int32 words (k_w / p_w: their bit patterns); host == NULL: its length.
+//  0 rowptr  1 src  2 dst  3 perm  4 t_rowptr  5 t_dst  6 t_eid  7 t_pos  8 ids  9 inv  10 k_rowptr  11 k_src  12 k_eid
+//  13 p_rowptr  14 p_src  15 p_eid  16 k_w  17 p_w
+extern "C" int64_t bsms_plan_export_ex(const bsms_plan_t* p, int which, int32_t* host) {
+  if (!p) return -1;
+  const int32_t* ptr = nullptr;
+  int64_t n = 0;
+  switch (which) {
+    case 0: ptr = p->rowptr; n = p->N + 1; break;
+    case 1: ptr = p->src; n = p->E; break;
+    case 2: ptr = p->dst; n = p->E; break;
+    case 3: ptr = p->perm; n = p->E; break;
+    case 4: ptr = p->t_rowptr; n = p->N + 1; break;
+    case 5: ptr = p->t_dst; n = p->E; break;
+    case 6: ptr = p->t_eid; n = p->E; break;
+    case 7: ptr = p->t_pos; n = p->E; break;
+    case 8: ptr = p->ids; n = p->ids ? p->Nk : 0; break;
+    case 9: ptr = p->inv; n = p->ids ? p->N : 0; break;
+    case 10: ptr = p->k_rowptr; n = p->ids ? p->Nk + 1 : 0; break;
+    case 11: ptr = p->k_src; n = p->Ek; break;
+    case 12: ptr = p->k_eid; n = p->Ek; break;
+    case 13: ptr = p->p_rowptr; n = p->ids ? p->N + 1 : 0; break;
+    case 14: ptr = p->p_src; n = p->Ep; break;
+    case 15: ptr = p->p_eid; n = p->Ep; break;
+    case 16: ptr = reinterpret_cast<const int32_t*>(p->k_w); n = p->w_bound ? p->Ek : 0; break;
+    case 17: ptr = reinterpret_cast<const int32_t*>(p->p_w); n = p->w_bound ? p->Ep : 0; break;
+    default: return -1;
+  }
+  if (host && n > 0 && ptr) {
+    if (hipMemcpy(host, ptr, size_t(n) * 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  }
+  return n;
 }
 
 extern "C" int bsms_plan_destroy(bsms_plan_t* p) {

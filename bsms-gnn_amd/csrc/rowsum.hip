@@ -594,6 +594,84 @@ __global__ __launch_bounds__(256) void k_bind_ew(const float* ew, const int32_t*
 }
 }  // namespace
 
+// ---- bsms_plan_concat (host side in plan.hip): blockIdx.y = part, the threads of the x dimension stride over the longest array of
+// the part; every array of the part is copied to its place in the union with the offsets of common.h: CatPart added.  Entry N_b of
+// a part's rowptr arrays coincides with entry 0 of the next part's (same value): a benign double write.
+namespace {
+struct PlanView {
+  const int32_t *rowptr, *t_rowptr, *src, *dst, *perm, *t_dst, *t_eid, *t_pos;
+  const int32_t *ids, *inv, *k_rowptr, *k_src, *k_eid, *p_rowptr, *p_src, *p_eid, *k_w, *p_w;
+};
+__device__ __forceinline__ PlanView view_of(const int32_t* blk, const int32_t* pool, int64_t N, int64_t E, int64_t Nk, int64_t Ek, int64_t Ep) {
+  PlanView v;
+  const size_t nN = idx_pad(size_t(N) + 1), nE = idx_pad(size_t(E));
+  v.rowptr = blk; v.t_rowptr = blk + nN; v.src = v.t_rowptr + nN; v.dst = v.src + nE; v.perm = v.dst + nE;
+  v.t_dst = v.perm + nE; v.t_eid = v.t_dst + nE; v.t_pos = v.t_eid + nE;
+  const size_t nK = idx_pad(size_t(Nk)), nNinv = idx_pad(size_t(N)), nK1 = idx_pad(size_t(Nk) + 1), nEk = idx_pad(size_t(Ek)), nEp = idx_pad(size_t(Ep));
+  v.ids = pool; v.inv = pool + nK; v.k_rowptr = v.inv + nNinv; v.k_src = v.k_rowptr + nK1; v.k_eid = v.k_src + nEk;
+  v.p_rowptr = v.k_eid + nEk; v.p_src = v.p_rowptr + nN; v.p_eid = v.p_src + nEp; v.k_w = v.p_eid + nEp; v.p_w = v.k_w + nEk;
+  return v;
+}
+__global__ __launch_bounds__(256) void k_plan_concat(bsms::CatArgs a) {
+  const bsms::CatPart c = a.part[blockIdx.y];
+  const PlanView in = view_of(c.blk, c.pool, c.N, c.E, c.Nk, c.Ek, c.Ep);
+  const PlanView o = view_of(a.out_blk, a.out_pool, a.N, a.E, a.Nk, a.Ek, a.Ep);
+  int32_t* const* ow = reinterpret_cast<int32_t* const*>(&o);   // (the union's arrays are written: same layout, mutable block)
+  auto W = [&](const int32_t* field) { return const_cast<int32_t*>(field); };
+  (void)ow;
+  const int longest = max(max(c.N + 1, c.E), max(max(c.Nk + 1, c.Ek), c.Ep));
+  const bool pooled = a.out_pool != nullptr;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < longest; i += gridDim.x * blockDim.x) {
+    if (i <= c.N) {
+      W(o.rowptr)[c.n_off + i] = in.rowptr[i] + c.e_off;
+      W(o.t_rowptr)[c.n_off + i] = in.t_rowptr[i] + c.e_off;
+      if (pooled) W(o.p_rowptr)[c.n_off + i] = in.p_rowptr[i] + c.ep_off;
+    }
+    if (i < c.N && pooled) {
+      const int32_t v = in.inv[i];
+      W(o.inv)[c.n_off + i] = v < 0 ? -1 : v + c.k_off;
+    }
+    if (i < c.E) {
+      const int32_t sq = in.src[i] + c.n_off, dq = in.dst[i] + c.n_off, pq = in.perm[i] + c.e_off;
+      W(o.src)[c.e_off + i] = sq;
+      W(o.dst)[c.e_off + i] = dq;
+      W(o.perm)[c.e_off + i] = pq;
+      W(o.t_dst)[c.e_off + i] = in.t_dst[i] + c.n_off;
+      W(o.t_eid)[c.e_off + i] = in.t_eid[i] + c.e_off;
+      W(o.t_pos)[c.e_off + i] = in.t_pos[i] + c.e_off;
+      if (a.coo_out) { a.coo_out[pq] = sq; a.coo_out[int64_t(a.E) + pq] = dq; }   // plan slot -> the caller's edge id
+    }
+    if (pooled) {
+      if (i <= c.Nk) W(o.k_rowptr)[c.k_off + i] = in.k_rowptr[i] + c.ek_off;
+      if (i < c.Nk) {
+        const int32_t v = in.ids[i] + c.n_off;
+        W(o.ids)[c.k_off + i] = v;
+        if (a.ids_out) a.ids_out[c.k_off + i] = v;
+      }
+      if (i < c.Ek) {
+        W(o.k_src)[c.ek_off + i] = in.k_src[i] + c.n_off;
+        W(o.k_eid)[c.ek_off + i] = in.k_eid[i] + c.e_off;
+        if (a.has_w) W(o.k_w)[c.ek_off + i] = in.k_w[i];
+      }
+      if (i < c.Ep) {
+        W(o.p_src)[c.ep_off + i] = in.p_src[i] + c.k_off;   // COARSE row of the target
+        W(o.p_eid)[c.ep_off + i] = in.p_eid[i] + c.e_off;
+        if (a.has_w) W(o.p_w)[c.ep_off + i] = in.p_w[i];
+      }
+    }
+  }
+}
+}  // namespace
+
+int bsms::launch_plan_concat(const CatArgs& a, hipStream_t s) {
+  int longest = 1;
+  for (int b = 0; b < a.nparts; ++b)
+    longest = std::max(longest, std::max(std::max(a.part[b].N + 1, a.part[b].E), std::max(std::max(a.part[b].Nk + 1, a.part[b].Ek), a.part[b].Ep)));
+  hipLaunchKernelGGL(k_plan_concat, dim3((unsigned)std::min<int64_t>(ceil_div(longest, 256), 64), (unsigned)a.nparts), dim3(256), 0, s, a);
+  BSMS_LAUNCH_CHECK();
+  return BSMS_OK;
+}
+
 extern "C" int bsms_plan_bind_edge_weights(bsms_plan_t* p, const float* ew, bsms_stream_t stream) {
   BSMS_REQUIRE(p != nullptr, BSMS_E_INVALID_ARG, "plan_bind_edge_weights: plan is null");
   if (!ew) { p->w_bound = nullptr; return BSMS_OK; }

@@ -82,6 +82,37 @@ class LevelPlan:
             pass
         return self._h
 
+    @classmethod
+    def from_handle(cls, handle, device):
+        """Wrap a `bsms_plan_t*` the library created itself (bsms_plan_concat); ownership passes to the wrapper."""
+        self = cls.__new__(cls)
+        with _COUNT_LOCK:
+            LevelPlan.constructed += 1
+            self.uid = LevelPlan.constructed
+        L = _abi.lib()
+        self.device = torch.device(device)
+        self._h = handle
+        self._used = set()
+        self.N, self.E, self.Nk = int(L.bsms_plan_num_nodes(handle)), int(L.bsms_plan_num_edges(handle)), int(L.bsms_plan_num_pooled(handle))
+        self.max_source, self.min_out_degree = int(L.bsms_plan_max_source(handle)), int(L.bsms_plan_min_out_degree(handle))
+        return self
+
+    ARRAYS = ("rowptr", "src", "dst", "perm", "t_rowptr", "t_dst", "t_eid", "t_pos", "ids", "inv", "k_rowptr", "k_src", "k_eid",
+              "p_rowptr", "p_src", "p_eid", "k_w", "p_w")
+
+    def export_ex(self):
+        """Every index array of the plan (include/bsms_hip.h: bsms_plan_export_ex) as {name: int32 numpy array} -- for tests."""
+        L, out = _abi.lib(), {}
+        for which, name in enumerate(self.ARRAYS):
+            n = int(L.bsms_plan_export_ex(self._h, which, None))
+            if n < 0:
+                raise _abi.BsmsError(f"bsms_plan_export_ex({name})")
+            a = np.empty(n, np.int32)
+            if n and int(L.bsms_plan_export_ex(self._h, which, a.ctypes.data)) != n:
+                raise _abi.BsmsError(f"bsms_plan_export_ex({name})")
+            out[name] = a
+        return out
+
     def export(self):
         """(rowptr, src_sorted, perm, t_rowptr) as int32 numpy arrays -- for tests."""
         rp = np.empty(self.N + 1, np.int32)
@@ -362,3 +393,97 @@ def collate_variable_meshes(samples):
             face=None if parts[0].face is None else torch.cat([d.face + o for d, o in zip(parts, offs)], dim=-1),
             x=cat([d.x for d in parts], 0), y=cat([d.y for d in parts], 0), mask=cat([d.mask for d in parts], 0)))
     return out
+
+
+# ------------------------------------------------------------------------------------ variable meshes, collated on the device
+def concat_plans(parts, ew_cat=None, want_index=True):
+    """Block-diagonal union of the LevelPlans `parts` built on the GPU (bsms_plan_concat): (plan, edge_index [2, E] int64, kept ids
+    [Nk] int64 or None) -- what `collate_variable_meshes` + `LevelPlan(...)` would give for the same meshes, without a host CSR
+    build or an upload.  `ew_cat`: concatenation of the parts' BOUND edge-weight tensors (the union is then bound to it).
+    Stream-ordered on the current stream."""
+    from .ops import _stream
+    L = _abi.lib()
+    dev = parts[0].device
+    E, Nk = sum(q.E for q in parts), sum(q.Nk for q in parts)
+    pooled = parts[0].Nk > 0
+    coo = torch.empty(2, E, dtype=torch.int64, device=dev) if want_index else None
+    ids = torch.empty(Nk, dtype=torch.int64, device=dev) if (want_index and pooled) else None
+    pl, keep = _abi.ptr_array([q.handle.value if hasattr(q.handle, "value") else q.handle for q in parts])
+    out = C.c_void_p()
+    with torch.cuda.device(dev):
+        _abi.check(L.bsms_plan_concat(pl, len(parts), None if ew_cat is None else ew_cat.data_ptr(),
+                                      None if coo is None else coo.data_ptr(), None if ids is None else ids.data_ptr(),
+                                      _stream(), C.byref(out)), "bsms_plan_concat")
+    plan = LevelPlan.from_handle(out, dev)
+    plan._parts = tuple(parts)          # the union copied the parts' arrays: nothing is shared, but a reader may want to know
+    if ew_cat is not None:
+        plan._ew_bound = ew_cat         # bound by ADDRESS: the plan keeps the tensor alive (ops._bind_edge_weights)
+    return plan, coo, ids
+
+
+class MeshBank:
+    """Per-MESH device state for variable-mesh training (the reference's cylinder_flow path, `consistent_mesh: false`: every
+    batch is a new combination of meshes, datasets/base.py:319-351).  A mesh's hierarchy is uploaded ONCE, its plans (CSR,
+    transpose, pooled transitions) and its edge-weight chain are built ONCE and stay in HBM; `collate(samples)` then assembles a
+    batch on the GPU: one `bsms_plan_concat` per level + one concatenation of the cached edge weights per level -- no host
+    collate of index lists, no index upload, no CSR build.  The result is what `collate_variable_meshes` + `.to(device)` give
+    (same tensors, PyG `Batch` semantics), with the plans and the edge-weight chain of the batch already in the engine's caches.
+
+    `process`: the model's BSGMP (it owns `prepare`, the per-hierarchy plan / edge-weight construction)."""
+
+    def __init__(self, process, device, capacity=4096):
+        self.process, self.device, self.capacity = process, torch.device(device), capacity
+        self._by_obj, self._by_content = OrderedDict(), OrderedDict()
+
+    def entry(self, levels):
+        """The resident state of ONE mesh, given its per-level LevelData (host): looked up by the identity of its level-0 edge
+        tensor first (a dataset that keeps its meshes in memory hands out the same objects), by content otherwise."""
+        k = id(levels[0].edge_index)
+        hit = self._by_obj.get(k)
+        if hit is not None and hit[0] is levels[0].edge_index:
+            return hit[1]
+        dev_idx = [(intern_index(d.edge_index, self.device), None if d.face is None else intern_index(d.face, self.device)) for d in levels]
+        ck = tuple((id(g), None if f is None else id(f)) for g, f in dev_idx)      # interned: equal content -> the same device tensors
+        ent = self._by_content.get(ck)
+        if ent is None:
+            depth = len(levels) - 1
+            m_gs, m_ids = [g for g, _ in dev_idx], [f for _, f in dev_idx[:depth]]
+            plans, ews, bottom = self.process.prepare(m_ids, m_gs, int(levels[0].num_nodes), self.device)
+            ent = dict(plans=[*plans, bottom], ews=list(ews), keep=dev_idx)
+            self._by_content[ck] = ent
+            while len(self._by_content) > self.capacity:
+                self._by_content.popitem(last=False)
+        self._by_obj[k] = (levels[0].edge_index, ent)
+        while len(self._by_obj) > self.capacity:
+            self._by_obj.popitem(last=False)
+        return ent
+
+    def collate(self, samples):
+        """`samples`: list of per-sample lists of host LevelData (what `collate_variable_meshes` takes).  Returns the per-level
+        device LevelData of the block-diagonal batch."""
+        ents = [self.entry(s) for s in samples]
+        depth = len(samples[0]) - 1
+        cat0 = lambda get: None if get(samples[0][0]) is None else _upload(torch.cat([get(s[0]) for s in samples], 0), self.device)
+        x, y, mask = cat0(lambda d: d.x), cat0(lambda d: d.y), cat0(lambda d: d.mask)
+        out, plans, ews = [], [], []
+        for lvl in range(depth + 1):
+            parts = [e["plans"][lvl] for e in ents]
+            ew_cat = torch.cat([e["ews"][lvl] for e in ents]) if lvl < depth else None
+            # the union may take the parts' gathered weight copies only if every part is bound to ITS OWN chain tensor (a coarse plan
+            # shared by two hierarchies keeps the first binding, ops._bind_edge_weights): otherwise the union stays unbound
+            bound = ew_cat is not None and all((_abi.lib().bsms_plan_bound_edge_weights(q.handle) or 0) == e["ews"][lvl].data_ptr()
+                                               for q, e in zip(parts, ents))
+            plan, coo, ids = concat_plans(parts, ew_cat if bound else None)
+            key = (_key(coo), plan.N, _key(ids) if ids is not None else None)
+            with _LOCK:                                   # the engine's lookup by tensor identity (plan_for / plans_for) hits
+                _CACHE._d[key] = (plan, coo.untyped_storage(), ids.untyped_storage() if ids is not None else None)
+                while len(_CACHE._d) > _CACHE.capacity:
+                    _CACHE._d.popitem(last=False)
+            plans.append(plan)
+            if ew_cat is not None:
+                ews.append(ew_cat)
+            out.append(LevelData(edge_index=coo, num_nodes=plan.N, face=ids, x=x if lvl == 0 else None, y=y if lvl == 0 else None,
+                                 mask=mask if lvl == 0 else None))
+        if depth > 0:
+            plans[0]._ew_chain = (tuple(q.uid for q in plans[:depth]), ews)   # BSGMP._edge_weights: the chain of this hierarchy, ready
+        return out

@@ -123,9 +123,24 @@ int64_t bsms_plan_num_edges(const bsms_plan_t* plan);
 int64_t bsms_plan_num_pooled(const bsms_plan_t* plan);  /* Nk, 0 if no pool attached */
 int64_t bsms_plan_min_out_degree(const bsms_plan_t* plan);
 int64_t bsms_plan_max_source(const bsms_plan_t* plan);  /* max(g[0]); degree() length-1, utils/basic.py:305 */
+/* Block-diagonal union of `nparts` plans, built ON THE DEVICE from the parts' index blocks (one kernel per 16 parts on `stream`;
+ * no host CSR build, no upload): the plan of a batch of DIFFERENT meshes -- the reference's variable-mesh path, PyG `Batch`
+ * collation of datasets/base.py:325-349 consumed at models/model.py:194-200 -- from per-mesh plans that stay resident in HBM.
+ * Equal, array for array, to bsms_plan_create on the offset-concatenated edge list + bsms_plan_set_pool on the offset kept ids
+ * (all parts have pools, or none).  `ew_cat` (nullable): the DEVICE concatenation of the parts' bound edge-weight tensors, in part
+ * order; every part must then be bound (bsms_plan_bind_edge_weights), the union is bound to `ew_cat` and its gathered weight
+ * copies are the parts'.  `coo_out` (nullable): DEVICE int64 [2, E] that receives the union's edge list in the caller's edge
+ * order; `ids_out` (nullable): DEVICE int64 [Nk], its kept ids (what PyG's Batch would have produced).  The arrays of the new
+ * plan are complete in STREAM ORDER: use it on `stream`, or synchronise first. */
+int bsms_plan_concat(const bsms_plan_t* const* parts, int nparts, const float* ew_cat, int64_t* coo_out, int64_t* ids_out,
+                     bsms_stream_t stream, bsms_plan_t** out);
 /* debug/test accessors: copy index arrays to HOST int32 buffers (sizes N+1, E, E, E). */
 int bsms_plan_export(const bsms_plan_t* plan, int32_t* rowptr, int32_t* src_sorted,
                      int32_t* perm, int32_t* t_rowptr);
+/* array `which` of a plan as int32 words on the HOST (host == NULL: only its length is returned; < 0: error):
+ * 0 rowptr 1 src 2 dst 3 perm 4 t_rowptr 5 t_dst 6 t_eid 7 t_pos 8 ids 9 inv 10 k_rowptr 11 k_src 12 k_eid 13 p_rowptr 14 p_src
+ * 15 p_eid 16 k_w 17 p_w (bit patterns of the gathered edge weights; length 0 while unbound).  Synchronises the device. */
+int64_t bsms_plan_export_ex(const bsms_plan_t* plan, int which, int32_t* host);
 
 /* ---------------------------------------------------------------- A1: edge aggregation ------
  * scatter_sum(src, index=g[1], dim=-2, dim_size=N)  (utils/basic.py:324-343, call site

@@ -61,6 +61,26 @@ for b in batches:
     dp.step_loss_backward(to_dev(b), False)
 torch.cuda.synchronize()
 print(f"fresh, pipelined (upload + plans + step, no sync): {(time.perf_counter() - t0) / N * 1e3:7.2f} ms/step")
+# ---- round 6: the same stream of fresh batches assembled ON THE DEVICE from per-mesh plans that stay in HBM (graph.MeshBank:
+# bsms_plan_concat per level, cached edge weights concatenated; no index collate, no index upload, no CSR build)
+bank = eng.MeshBank(sim.process, "cuda")
+def samples():
+    return [pool[i] for i in torch.randperm(len(pool), generator=perm)[:B].tolist()]
+for _ in range(WARM):
+    dp.step_loss_backward(bank.collate(samples()), False)
+torch.cuda.synchronize()
+tc = tstep = 0.0
+for _ in range(N):
+    t0 = time.perf_counter(); d = bank.collate(samples()); torch.cuda.synchronize(); t1 = time.perf_counter()
+    dp.step_loss_backward(d, False); torch.cuda.synchronize(); t2 = time.perf_counter()
+    tc += t1 - t0; tstep += t2 - t1
+print(f"fresh batch, MeshBank (synchronised): collate {tc / N * 1e3:7.2f} ms  step {tstep / N * 1e3:7.2f} ms   plans built {eng.graph.LevelPlan.constructed}")
+todo = [samples() for _ in range(N)]
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for sm in todo:
+    dp.step_loss_backward(bank.collate(sm), False)
+torch.cuda.synchronize()
+print(f"fresh, pipelined, MeshBank (device collate + step, no sync): {(time.perf_counter() - t0) / N * 1e3:7.2f} ms/step")
 if os.environ.get("FRESH_PROFILE"):
     import cProfile, pstats
     pr = cProfile.Profile()
@@ -86,3 +106,11 @@ for name, wrap in (("Trainer.iter", lambda it: it), ("Trainer.iter behind Device
         tr.iter(b)
     torch.cuda.synchronize()
     print(f"fresh batches, {name}: {(time.perf_counter() - t0) / N * 1e3:7.2f} ms/step")
+for _ in range(20):
+    tr.iter(tr.collate(samples()))
+todo = [samples() for _ in range(N)]
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for sm in todo:
+    tr.iter(tr.collate(sm))
+torch.cuda.synchronize()
+print(f"fresh batches, Trainer.iter(Trainer.collate(samples)) [MeshBank]: {(time.perf_counter() - t0) / N * 1e3:7.2f} ms/step")

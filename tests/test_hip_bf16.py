@@ -213,6 +213,13 @@ def test_surface_b2_bf16_full_size(eng):
     assert abs(res["bf16"][1] - res["f32"][1]) < 1e-2 * abs(res["f32"][1])
     assert set(res["bf16"][2]) == set(res["f32"][2])
     _grads_close(res["bf16"][2], res["f32"][2], "surface B=2 L=6 D=256 p=3 bf16 vs fp32 engine (fused step)")
+    # Round 6 ("What's weak" 1b): prediction and loss of BOTH bf16 precisions also against the INDEPENDENT CPU
+    # emulation of the arithmetic (oracle/bf16_oracle.py) at full size, as the airfoil test does -- not only engine against engine
+    for prec, node_level in (("bf16", False), ("bf16_nodes", True)):
+        pred_e, loss_e = _emulated_prediction("surface", 2, node_level)
+        e_pred, e_loss = rel_err(res[prec][0].cpu(), pred_e), abs(res[prec][1] - loss_e) / abs(loss_e)
+        print(f"[surface B=2 {prec}] vs CPU emulation: prediction {e_pred:.2e}, loss {e_loss:.2e}")
+        assert e_pred < 1e-2 and e_loss < 2e-3, (prec, e_pred, e_loss)
 
 
 def _emulated_prediction(kind, batch, node_level):
