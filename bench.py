@@ -398,6 +398,7 @@ def other_lines(sim_airfoil, data_airfoil, loss_f32, warmup=10, steps=30):
       airfoil_bf16 / airfoil_bf16_nodes   BASELINE configs[2]: the headline workload in the BSMS_BF16 / BSMS_BF16_NODES precision
       surface_b2_bf16                      configs[4] per GPU: 16384 nodes, 6 levels, D=256, pos_dim 3, batch 2
       cylinder_b8 / cylinder_b8_blockdiag  configs[1]: dense batch of one mesh / 8 different meshes in one block-diagonal batch
+      cylinder_b8_fresh_batches_*          configs[1] as the reference trains it: a NEW combination of 8 meshes every step
     `loss_vs_f32` = |loss - fp32 loss| / fp32 loss of the SAME engine, model and batch; `loss_vs_oracle` (cylinder, dense) =
     against the CPU oracle's forward on the same seed."""
     import gc
@@ -454,6 +455,24 @@ def other_lines(sim_airfoil, data_airfoil, loss_f32, warmup=10, steps=30):
     gc.collect(); torch.cuda.empty_cache()
     wl, sim, data, consistent = fresh("cylinder", 8, blockdiag=True)
     out["cylinder_b8_blockdiag"] = run(sim, data, consistent, "f32")
+    # Round 6: the reference's ACTUAL cylinder path -- a shuffled loader hands the trainer a NEW combination of meshes every step
+    # (consistent_mesh: false, datasets/base.py:319-351), so nothing mesh-dependent of the BATCH is cached.  16 meshes, a random
+    # 8 of them per step; (a) host collate + upload + plans from edge lists (rounds 3-5), (b) graph.MeshBank: per-mesh plans and edge
+    # weights resident in HBM, the batch assembled by bsms_plan_concat.  Timed region = collate + step, no synchronisation inside.
+    try:
+        meshes = build_blockdiag_workload("cylinder", 16, "cpu")["samples"]
+        sim.process.precision = "f32"
+        dp = eng.DataParallel(sim)
+        gen = torch.Generator().manual_seed(1)
+        pick = lambda: [meshes[i] for i in torch.randperm(len(meshes), generator=gen)[:8].tolist()]
+        bank = eng.MeshBank(sim.process, "cuda")
+        host_batch = lambda: [d.to("cuda", intern=True) for d in eng.collate_variable_meshes(pick())]
+        for name, make in (("host_collate", host_batch), ("mesh_bank", lambda: bank.collate(pick()))):
+            v, ms, loss = timed_steps(lambda: dp.step_loss_backward(make(), False), 2 * warmup, steps)
+            out[f"cylinder_b8_fresh_batches_{name}"] = {"value": v, "unit": "steps/s", "ms_per_step": ms, "steps": steps, "dtype": "f32", "loss": loss,
+                                                        "what": "every step a new random 8 of 16 different cylinder meshes; timed: collate + upload + plans + step"}
+    except Exception as e:  # noqa: BLE001
+        out["cylinder_b8_fresh_batches"] = f"not measured: {e}"
     return out
 
 
