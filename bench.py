@@ -459,7 +459,11 @@ def other_lines(sim_airfoil, data_airfoil, loss_f32, warmup=10, steps=30):
     # (consistent_mesh: false, datasets/base.py:319-351), so nothing mesh-dependent of the BATCH is cached.  16 meshes, a random
     # 8 of them per step; (a) host collate + upload + plans from edge lists (rounds 3-5), (b) graph.MeshBank: per-mesh plans and edge
     # weights resident in HBM, the batch assembled by bsms_plan_concat.  Timed region = collate + step, no synchronisation inside.
+    threads = torch.get_num_threads()
     try:
+        # host-side tensor work (collate, hashing) with PyTorch's default of one intra-op thread per LOGICAL cpu gets a process on a small
+        # cgroup quota throttled for whole scheduler periods (measured: 56 ms per step instead of 4; profiles/fresh_mesh.py does the same)
+        torch.set_num_threads(max(1, min(usable_cpus() // 2, 8)))
         meshes = build_blockdiag_workload("cylinder", 16, "cpu")["samples"]
         sim.process.precision = "f32"
         dp = eng.DataParallel(sim)
@@ -473,6 +477,8 @@ def other_lines(sim_airfoil, data_airfoil, loss_f32, warmup=10, steps=30):
                                                         "what": "every step a new random 8 of 16 different cylinder meshes; timed: collate + upload + plans + step"}
     except Exception as e:  # noqa: BLE001
         out["cylinder_b8_fresh_batches"] = f"not measured: {e}"
+    finally:
+        torch.set_num_threads(threads)
     return out
 
 
