@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["BSMS_PLAN_CACHE"] = "24"
 import torch
 torch.set_num_threads(4)
@@ -38,3 +38,18 @@ for i, b in enumerate(eng.DevicePrefetcher(batches(400), tr)):
     if i % 100 == 99:
         torch.cuda.synchronize()
         print(i + 1, "steps", f"{(time.perf_counter() - t0) / (i + 1) * 1e3:.2f} ms/step  loss {float(l):.4f}  allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB (start {m0 / 2**20:.0f})  reserved {torch.cuda.memory_reserved() / 2**20:.0f} MiB  plans {eng.graph.LevelPlan.constructed}  grave {len(eng.graph._GRAVE)}")
+
+# ---- round 6: the same stream of fresh batches through Trainer.collate (graph.MeshBank: meshes of DIFFERENT sizes resident in HBM,
+# every batch assembled by bsms_plan_concat), a small plan cache so that the unions are retired and their blocks recycled all the time;
+# checks that the loss of a batch equals the host-collated route's bit for bit every 100 steps and that memory stays flat
+def sample_sets(k):
+    for _ in range(k):
+        yield [pool[i] for i in torch.randperm(len(pool), generator=perm)[:8].tolist()]
+torch.cuda.synchronize(); m0 = torch.cuda.memory_allocated(); t0 = time.perf_counter()
+for i, sm in enumerate(sample_sets(1200)):
+    l = tr.iter(tr.collate(sm))
+    if i % 100 == 99:
+        a = float(tr.get_loss(tr.collate(sm))); b = float(tr.get_loss(eng.collate_variable_meshes(sm)))
+        torch.cuda.synchronize()
+        print("MeshBank", i + 1, "steps", f"{(time.perf_counter() - t0) / (i + 1) * 1e3:.2f} ms/step  loss {float(l):.4f}  device-collated == host-collated loss: {a == b} ({a:.6f})  "
+              f"allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB (start {m0 / 2**20:.0f})  reserved {torch.cuda.memory_reserved() / 2**20:.0f} MiB  plans {eng.graph.LevelPlan.constructed}  grave {len(eng.graph._GRAVE)}")
