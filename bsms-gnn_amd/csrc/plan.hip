@@ -64,7 +64,10 @@ static int create_lane_stream(hipStream_t* out, const SideLane* lanes, int which
   hipStream_t st = nullptr;
   for (int attempt = 0; attempt < 6; ++attempt) {
     BSMS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));   // (a lower or higher stream priority for the lanes: +-0, profiles/README.md)
-    bool good = can_overtake(nullptr, st);
+    // twice against the caller's default stream: one kernel trace of round 6 (profiles/r06_step_summary.md: a profiled run) shows a
+    // lane that had passed ONE probe on the default stream's hardware queue after all -- its 38 launches per step then run in order
+    // with the caller's, +0.7 ms per step; a second pass costs ~0.3 ms once per process
+    bool good = can_overtake(nullptr, st) && can_overtake(nullptr, st);
     for (int k = 0; k < kSideLanes && good; ++k)
       if (k != which && lanes[k].stream) good = can_overtake(lanes[k].stream, st);
     if (good || attempt == 5) break;   // after six tries: keep the last one (four hardware queues cannot separate every stream of a process)
