@@ -198,30 +198,38 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
   const bool packs_ok = !training && (reuse & 1), pos_ok = !training && (reuse & 2);
   SideLane *lane = nullptr, *lane0 = nullptr;
   auto packs_of = [&](int k) { return training ? nullptr : w.packs[k]; };
+  for (int i = 0; i < L; ++i) {
+    pos_l[i + 1] = v.pos[i + 1];
+    pstride_l[i + 1] = pos_batch_stride ? s.N[i + 1] * p : 0;
+  }
+  // The lanes FORK here (in front of block 0) but their launches are enqueued BEHIND block 0's: the 15 small lane kernels
+  // come first in time on the GPU either way, and enqueued first they kept the caller's stream waiting for the host --
+  // block 0 started 80-210 us late in every step of the round-6 traces (profiles/r06_step_start_gap.txt).
   if (L > 0) {
     if (!pos_ok && ((rc = side_lane(&lane, 1, st)) || (rc = side_fork(lane, st)))) return rc;
-    for (int i = 0; i < L; ++i) {
-      if (!pos_ok && (rc = bsms_edge_conv(plans[i], pos_l[i], posB, p, ew[i], 1, 1, v.pos[i + 1], lane->stream))) return rc;
-      pos_l[i + 1] = v.pos[i + 1];
-      pstride_l[i + 1] = pos_batch_stride ? s.N[i + 1] * p : 0;
-    }
+    if (!packs_ok && ((rc = side_lane(&lane0, 0, st)) || (rc = side_fork(lane0, st)))) return rc;
+  }
+  auto enqueue_lanes = [&]() -> int {
+    int r;
+    for (int i = 0; i < L && !pos_ok; ++i)
+      if ((r = bsms_edge_conv(plans[i], pos_l[i], posB, p, ew[i], 1, 1, v.pos[i + 1], lane->stream))) return r;
     if (!packs_ok) {
       // two marks on the lane: the packs of the down path + bottom block (slot 0: waited for behind block 0) and those of the up path
       // (slot 1: waited for in front of the first up block).  One join behind block 0 made the caller's stream wait for all 2L
       // prepacks -- 130-160 us per step at D = 256, where a block's prepack takes 55 us (profiles/r05_surface_join_ab.txt)
-      if ((rc = side_lane(&lane0, 0, st)) || (rc = side_fork(lane0, st))) return rc;
       for (int k = 1; k <= 2 * L; ++k) {
         const int lv = level_of_block(k, L);
-        if ((rc = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream, precision))) return rc;
-        if ((k == L || k == 2 * L) && (rc = side_mark(lane0, k == L ? 0 : 1))) return rc;
+        if ((r = gmp_prepack(B, s.N[lv], s.E[lv], D, p, hidden, block(params, k, hidden), v.gmp[k], w.gmp, packs_of(k), lane0->stream, precision))) return r;
+        if ((k == L || k == 2 * L) && (r = side_mark(lane0, k == L ? 0 : 1))) return r;
       }
     }
-  }
+    return 0;
+  };
   const float* hi = h;
   for (int i = 0; i < L; ++i) {
     if ((rc = gmp_fwd_core(plans[i], hi, pos_l[i], B, D, p, pstride_l[i], hidden, block(params, i, hidden), w.skip[i], v.gmp[i], w.gmp,
                            packs_of(i), i == 0 && !packs_ok, nullptr, st, precision))) return rc;
-    if (i == 0 && ((lane && (rc = side_join(lane, st))) || (lane0 && (rc = side_wait_mark(lane0, 0, st))))) return rc;
+    if (i == 0 && ((rc = enqueue_lanes()) || (lane && (rc = side_join(lane, st))) || (lane0 && (rc = side_wait_mark(lane0, 0, st))))) return rc;
     // restrict the features to the kept nodes (ops/BSMS.py:74, 79-83)
     if ((rc = bsms_edge_conv(plans[i], w.skip[i], B, D, ew[i], 1, 1, v.hin[i + 1], stream))) return rc;
     hi = v.hin[i + 1];
