@@ -15,8 +15,9 @@ SOURCES = ["plan.hip", "rowsum.hip", "chain.hip", "efuse.hip", "efwd.hip", "wgra
 # compiles them into the experiment builds (-DBSMS_EXPERIMENTS), where gmp.hip / chain.hip keep their hooks
 HEADERS = ["common.h", "chain.h", "chain_dev.h", os.path.join("..", "..", "include", "bsms_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-if os.environ.get("BSMS_EXPERIMENTS") == "1":   # profiling / A-B builds only: BSMS_DEBUG_FLAGS, in-kernel time stamps
+if os.environ.get("BSMS_EXPERIMENTS") == "1":   # profiling / A-B builds only: BSMS_DEBUG_FLAGS, in-kernel time stamps, launch-shape knobs
     FLAGS.append("-DBSMS_EXPERIMENTS")
+    SOURCES = SOURCES + [os.path.join("experiments", "efuse32.hip")]   # the hooks gmp.hip keeps under BSMS_EXPERIMENTS need it to link
 
 
 def _hipcc():
@@ -43,7 +44,7 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
 
     def compile_one(src):
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
         # no contraction: rowsum.hip rounds x*ew before the add like the reference; sim.hip keeps the fp64 normaliser roundings
         extra = ["-ffp-contract=off"] if src in ("rowsum.hip", "sim.hip") else []
         if src == "chain.hip" and os.environ.get("BSMS_CHAIN_FLAGS"):   # A/B builds
