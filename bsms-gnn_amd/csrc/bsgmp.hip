@@ -204,7 +204,7 @@ extern "C" int bsms_bsgmp_fwd_p(const bsms_plan_t* const* plans, const float* co
   }
   // The lanes FORK here (in front of block 0) but their launches are enqueued BEHIND block 0's: the 15 small lane kernels
   // come first in time on the GPU either way, and enqueued first they kept the caller's stream waiting for the host --
-  // block 0 started 80-210 us late in every step of the round-6 traces (profiles/r06_step_start_gap.txt).
+  // block 0 started 80-210 us late in every step of the round-6 traces (profiles/r06_schedule_probes.txt).
   if (L > 0) {
     if (!pos_ok && ((rc = side_lane(&lane, 1, st)) || (rc = side_fork(lane, st)))) return rc;
     if (!packs_ok && ((rc = side_lane(&lane0, 0, st)) || (rc = side_fork(lane0, st)))) return rc;
