@@ -47,6 +47,7 @@ struct WgradTable {
   float* partials;   // [tiles][TB*TB]
   float* colsums;    // [tiles][TB]
   unsigned long long* timing;  // experiments only: per-workgroup s_memtime stamps (null in production)
+  int wide;          // k_wgrad_wide launch (D = 256): a tile is 128 rows x ALL 256 columns of dW, tile = split * nblk + bi
 };
 
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {  // exact: x = hi + mid + lo
@@ -369,6 +370,176 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// k_wgrad_wide (round 6): the fp16 x 2 jobs at D = 256.  k_wgrad cuts dW into four 128 x 128 blocks per slab there, so every
+// row of G and of A is read from HBM -- and split into its pieces -- TWICE (profiles/r06_surface_notes.txt: level 0 of the surface
+// step, 1.2 GB algorithmic, 730 us on 128 workgroups).  Here a workgroup owns 128 rows of dW (columns of G) x ALL 256 columns (of
+// A): A is read and split once, G twice; a wave owns 32 x 64 of dW = 2 x 4 MFMA blocks, i.e. 24 products per 12 fragment reads
+// where k_wgrad has 12 per 8.  Same staging, same step schedule, same products in the same order per accumulator (chunk after
+// chunk, rows ascending; h l, l h, h h) -- the results are bit-identical to k_wgrad<., false, true>.  LDS: 2 x [G h | G l | A h | A l]
+// = 2 x (2 x 9 KB + 2 x 17 KB) = 104 KB; the A planes have a 544-byte row pitch (136 dwords: again 8 banks further per row).
+constexpr int LROW_W = 272;
+constexpr int PLANE_W = RC * LROW_W;
+constexpr int BUF_W = 2 * PLANE + 2 * PLANE_W;
+
+__device__ __forceinline__ bf16x8 column_fragment_w(const short* plane, int col0, int lane) {   // column_fragment on a 272-short pitch
+  const int q = lane >> 4, ip = lane & 15;
+  const short* p = plane + (4 * q + (ip >> 2)) * LROW_W + col0 + 4 * (ip & 3);
+  using lds_s16x4 = __attribute__((address_space(3))) s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * LROW_W));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_wide(WgradTable tab) {
+  extern __shared__ __attribute__((aligned(16))) short planes[];  // [2 buffers][G h | G l | A h | A l]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int j = 0;
+  while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
+  const WgradJob job = tab.job[j];
+  const int local = blockIdx.x - tab.first_tile[j];
+  const int bi = local % tab.nblk, split = local / tab.nblk;
+  const int64_t r0 = int64_t(split) * tab.rows_per_wg[j];
+  const int64_t r1 = min(job.R, r0 + tab.rows_per_wg[j]);
+  const int nchunk = int((r1 - r0 + RC - 1) / RC);
+  const int n0 = bi * TB;
+  constexpr int TILE = TB * 2 * TB;   // floats per partial tile: [128][256]
+  // one power-of-two scale per operand tensor from its magnitude bound (k_wgrad, H2)
+  int Eg, Ea;
+  float sG, sA;
+  {
+    static_assert(kBoundWidth == 8 * WG_THREADS, "two float4 of each bound slot per thread");
+    __shared__ unsigned bred[2][WG_THREADS / 64];
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const u32x4* gs = reinterpret_cast<const u32x4*>(job.g_bound);
+    const u32x4* as = reinterpret_cast<const u32x4*>(job.a_bound);
+    const u32x4 gv = gs[tid], gw = gs[tid + WG_THREADS], av = as[tid], aw = as[tid + WG_THREADS];
+    unsigned gm = max(max(max(gv[0], gv[1]), max(gv[2], gv[3])), max(max(gw[0], gw[1]), max(gw[2], gw[3])));
+    unsigned am = max(max(max(av[0], av[1]), max(av[2], av[3])), max(max(aw[0], aw[1]), max(aw[2], aw[3])));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      gm = max(gm, (unsigned)__shfl_xor((int)gm, o, 64));
+      am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+    }
+    if (lane == 0) { bred[0][wave] = gm; bred[1][wave] = am; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WG_THREADS / 64; ++w) { gm = max(gm, bred[0][w]); am = max(am, bred[1][w]); }
+    Eg = bound_exp(__uint_as_float(gm) * job.g_mul);
+    Ea = bound_exp(__uint_as_float(am) * job.a_mul);
+    sG = __uint_as_float(unsigned(268 - Eg) << 23);
+    sA = __uint_as_float(unsigned(268 - Ea) << 23);
+  }
+  // staging: one float4 of G (columns n0 + 4 (tid % 32) ..) and two of A (columns 4 (tid % 32) .. and 128 further) per thread and
+  // chunk, row tid / 32: every load instruction covers full 512-byte bursts of 32 rows
+  const int srow = tid >> 5, scol = (tid & 31) * 4;
+  const float* gsrc = job.G + n0 + scol;
+  const float* asrc = job.A + scol;
+  const int64_t rlast = r1 - 1;
+  constexpr int NPW = 2;   // register sets: two 64 KB chunks in flight per workgroup (k_wgrad: three of 32 KB); a third set spills at 128 VGPRs
+  f32x4 sg[NPW], sa[NPW][2];
+  bool live[NPW];
+  auto fetch = [&](int chunk, int set) {   // chunks past the slab re-read its last rows (never staged)
+    const int64_t r = r0 + int64_t(chunk) * RC + srow;
+    live[set] = r < r1;
+    const int64_t rc = r < r1 ? r : rlast;
+    sg[set] = *reinterpret_cast<const f32x4*>(gsrc + rc * job.ldg);
+    sa[set][0] = *reinterpret_cast<const f32x4*>(asrc + rc * job.lda);
+    sa[set][1] = *reinterpret_cast<const f32x4*>(asrc + rc * job.lda + TB);
+  };
+  const bool want_db = job.db != nullptr;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  auto stash = [&](int set, int buf) {
+    short* dst = planes + buf * BUF_W;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    u32x2 h, l;
+    const f32x4 gq = live[set] ? sg[set] : zero;
+    split_quad_h2(gq, sG, h, l);
+    *reinterpret_cast<u32x2*>(dst + srow * LROW + scol) = h;
+    *reinterpret_cast<u32x2*>(dst + PLANE + srow * LROW + scol) = l;
+    if (want_db) csum += gq;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const f32x4 aq = live[set] ? sa[set][u] : zero;
+      split_quad_h2(aq, sA, h, l);
+      *reinterpret_cast<u32x2*>(dst + 2 * PLANE + srow * LROW_W + scol + TB * u) = h;
+      *reinterpret_cast<u32x2*>(dst + 2 * PLANE + PLANE_W + srow * LROW_W + scol + TB * u) = l;
+    }
+  };
+  // 16 waves: wave owns dW rows [32 wr, +32) x cols [64 wc, +64) = 2 x 4 MFMA blocks
+  const int wr = wave >> 2, wc = wave & 3;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nchunk == 0) {   // cannot happen for a launched slab; keeps the unconditional loads in range
+    float* part0 = tab.partials + int64_t(blockIdx.x) * TILE;
+    for (int o = tid; o < TILE; o += WG_THREADS) part0[o] = 0.f;
+    if (want_db && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = 0.f;
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < NPW; ++c) fetch(c, c);
+  stash(0, 0);
+  fetch(NPW, 0);
+  wg_barrier();
+  auto multiply = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const short* buf = planes + BUF * BUF_W;
+    bf16x8 g_h[2], g_l[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      g_h[a] = column_fragment(buf, 32 * wr + 16 * a, lane);
+      g_l[a] = column_fragment(buf + PLANE, 32 * wr + 16 * a, lane);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const bf16x8 a_h = column_fragment_w(buf + 2 * PLANE, 64 * wc + 16 * b, lane);
+      const bf16x8 a_l = column_fragment_w(buf + 2 * PLANE + PLANE_W, 64 * wc + 16 * b, lane);
+      acc[0][b] = mma_h(g_h[0], a_l, acc[0][b]);
+      acc[1][b] = mma_h(g_h[1], a_l, acc[1][b]);
+      acc[0][b] = mma_h(g_l[0], a_h, acc[0][b]);
+      acc[1][b] = mma_h(g_l[1], a_h, acc[1][b]);
+      acc[0][b] = mma_h(g_h[0], a_h, acc[0][b]);
+      acc[1][b] = mma_h(g_h[1], a_h, acc[1][b]);
+    }
+  };
+  auto step = [&](int c, auto set1_tag, auto buf_tag) {
+    constexpr int SET1 = decltype(set1_tag)::value, BUF = decltype(buf_tag)::value;
+    stash(SET1, BUF ^ 1);          // past the last chunk this stages zeros nobody reads
+    fetch(c + 1 + NPW, SET1);
+    multiply(buf_tag);
+    wg_barrier();
+  };
+  using std::integral_constant;
+  for (int c = 0; c < nchunk; c += 2) {   // chunk c: register set c % 2, buffer c & 1; no conditional step (slabs are multiples of 6 chunks)
+    step(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    step(c + 1, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+  }
+  // D[row = 4 q + r][col = c] of block (a, b) = dW[n0 + 32 wr + 16 a + 4 q + r][64 wc + 16 b + c]
+  const int q = lane >> 4, cc = lane & 15;
+  float* part = tab.partials + int64_t(blockIdx.x) * TILE;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        part[(32 * wr + 16 * a + 4 * q + r) * (2 * TB) + 64 * wc + 16 * b + cc] = ldexpf(acc[a][b][r], Eg + Ea - 282);
+  if (want_db) {  // combine the 32 row-threads of each column quad in fixed order through LDS
+    f32x4* red = reinterpret_cast<f32x4*>(planes);
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < 32) {
+      f32x4 v = red[tid];
+      for (int l = 1; l < 32; ++l) v += red[l * 32 + tid];
+      *reinterpret_cast<f32x4*>(tab.colsums + int64_t(blockIdx.x) * TB + tid * 4) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // k_wgrad_bf64: the bf16 jobs (WgradJob::bf16: gradient and activation tensors stored as bf16, ONE product per fragment
 // pair) with 64-row chunks.  In k_wgrad<., true> a chunk is 32 rows = 8 KB per operand and a thread moves 8 bytes of each:
 // half the bytes in flight per CU of the fp32 form at the same step overhead, and the chunk step is paced by HBM latency
@@ -493,6 +664,124 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_bf64(WgradTable tab) {
   }
 }
 
+// k_wgrad_bf64_wide (round 6): k_wgrad_bf64 at D = 256 with the 128 x 256 tiles of k_wgrad_wide -- A (bf16 rows) is read once instead
+// of twice.  64-row chunks: a thread moves 16 bytes of G and 2 x 16 bytes of A; same products in the same order per accumulator.
+constexpr int PLANE2_W = RC2 * LROW_W;
+constexpr int BUF2_W = PLANE2 + PLANE2_W;   // [G | A]: 18 KB + 34 KB
+
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_bf64_wide(WgradTable tab) {
+  extern __shared__ __attribute__((aligned(16))) short planes[];  // [2 buffers][G 64 x LROW | A 64 x LROW_W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int j = 0;
+  while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
+  const WgradJob job = tab.job[j];
+  const int local = blockIdx.x - tab.first_tile[j];
+  const int bi = local % tab.nblk, split = local / tab.nblk;
+  const int64_t r0 = int64_t(split) * tab.rows_per_wg[j];
+  const int64_t r1 = min(job.R, r0 + tab.rows_per_wg[j]);
+  const int nchunk = int((r1 - r0 + RC2 - 1) / RC2);
+  const int n0 = bi * TB;
+  constexpr int TILE = TB * 2 * TB;
+  float* part = tab.partials + int64_t(blockIdx.x) * TILE;
+  const bool want_db = job.db != nullptr;
+  if (nchunk == 0) {   // cannot happen for a launched slab
+    for (int o = tid; o < TILE; o += WG_THREADS) part[o] = 0.f;
+    if (want_db && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = 0.f;
+    return;
+  }
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  const int srow = tid >> 4, scol = (tid & 15) * 8;
+  const unsigned short* gsrc = reinterpret_cast<const unsigned short*>(job.G) + n0 + scol;
+  const unsigned short* asrc = reinterpret_cast<const unsigned short*>(job.A) + scol;
+  const int64_t rlast = r1 - 1;
+  constexpr int NPW = 2;   // register sets: two 48 KB chunks in flight (a third set spills at 128 VGPRs)
+  u32x4 sg[NPW], sa[NPW][2];
+  bool live[NPW];
+  auto fetch = [&](int chunk, int set) {   // unconditional loads: chunks past the slab re-read its last row (never staged)
+    const int64_t r = r0 + int64_t(chunk) * RC2 + srow;
+    live[set] = r < r1;
+    const int64_t rc = r < r1 ? r : rlast;
+    sg[set] = *reinterpret_cast<const u32x4*>(gsrc + rc * job.ldg);
+    sa[set][0] = *reinterpret_cast<const u32x4*>(asrc + rc * job.lda);
+    sa[set][1] = *reinterpret_cast<const u32x4*>(asrc + rc * job.lda + TB);
+  };
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of G over this thread's rows
+  auto stash = [&](int set, int buf) {
+    short* dst = planes + buf * BUF2_W;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const u32x4 gq = live[set] ? sg[set] : zero;
+    *reinterpret_cast<u32x4*>(dst + srow * LROW + scol) = gq;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4*>(dst + PLANE2 + srow * LROW_W + scol + TB * u) = live[set] ? sa[set][u] : zero;
+    if (want_db) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        csum[2 * k] += __uint_as_float(gq[k] << 16);
+        csum[2 * k + 1] += __uint_as_float(gq[k] & 0xffff0000u);
+      }
+    }
+  };
+  const int wr = wave >> 2, wc = wave & 3;   // dW rows [32 wr, +32) x cols [64 wc, +64)
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](int buf) {
+    const short* base = planes + buf * BUF2_W;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {   // two K steps of 32 rows
+      const short* pg = base + ks * 32 * LROW;
+      const short* pa = base + PLANE2 + ks * 32 * LROW_W;
+      bf16x8 g1[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) g1[a] = column_fragment(pg, 32 * wr + 16 * a, lane);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bf16x8 a1 = column_fragment_w(pa, 64 * wc + 16 * b, lane);
+        acc[0][b] = mma(g1[0], a1, acc[0][b]);
+        acc[1][b] = mma(g1[1], a1, acc[1][b]);
+      }
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < NPW; ++c) fetch(c, c);
+  stash(0, 0);
+  fetch(NPW, 0);
+  wg_barrier();
+  auto step = [&](int c, auto set1_tag, auto buf_tag) {
+    constexpr int SET1 = decltype(set1_tag)::value, BUF = decltype(buf_tag)::value;
+    stash(SET1, BUF ^ 1);          // chunk c + 1 -> the other buffer (zeros past the slab)
+    fetch(c + 1 + NPW, SET1);
+    multiply(BUF);
+    wg_barrier();
+  };
+  using std::integral_constant;
+  for (int c = 0; c < nchunk; c += 2) {   // chunk c: register set c % 2, buffer c & 1
+    step(c, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    step(c + 1, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+  }
+  const int q = lane >> 4, cc = lane & 15;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(32 * wr + 16 * a + 4 * q + r) * (2 * TB) + 64 * wc + 16 * b + cc] = acc[a][b][r];
+  if (want_db) {  // the 64 row-threads of each column octet in fixed order through LDS
+    float* red = reinterpret_cast<float*>(planes);   // [64 row lanes][128 columns]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[srow * TB + scol + k] = csum[k];
+    __syncthreads();
+    if (tid < TB) {
+      float v = red[tid];
+      for (int l = 1; l < 64; ++l) v += red[l * TB + tid];
+      tab.colsums[int64_t(blockIdx.x) * TB + tid] = v;
+    }
+  }
+}
+
 // dW[n][col0+k] = sum over slabs of the partial blocks; db likewise.  A block owns 64 float4 outputs; its 4
 // "slab lanes" each sum every 4th slab (independent 16-byte loads in flight), then combine in a fixed order
 // through LDS, so the result does not depend on scheduling.
@@ -510,12 +799,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradTable tab) {
     if (o4 < nmat) {
       const int n = (o4 * 4) / D, k = (o4 * 4) % D;
       const int bi = n / TB, bj = k / TB;
-      base = tab.partials + int64_t(tab.first_tile[j] + bi * nblk + bj) * (TB * TB) + (n % TB) * TB + (k % TB);
-      stride = int64_t(nblk) * nblk * (TB * TB);
+      if (tab.wide) {   // k_wgrad_wide: tile = split * nblk + bi, [128][256] floats
+        base = tab.partials + int64_t(tab.first_tile[j] + bi) * (TB * 2 * TB) + (n % TB) * (2 * TB) + k;
+        stride = int64_t(nblk) * (TB * 2 * TB);
+      } else {
+        base = tab.partials + int64_t(tab.first_tile[j] + bi * nblk + bj) * (TB * TB) + (n % TB) * TB + (k % TB);
+        stride = int64_t(nblk) * nblk * (TB * TB);
+      }
     } else {
       const int n = (o4 - nmat) * 4, bi = n / TB;
-      base = tab.colsums + int64_t(tab.first_tile[j] + bi * nblk) * TB + (n % TB);
-      stride = int64_t(nblk) * nblk * TB;
+      base = tab.colsums + int64_t(tab.first_tile[j] + (tab.wide ? bi : bi * nblk)) * TB + (n % TB);
+      stride = int64_t(nblk) * (tab.wide ? 1 : nblk) * TB;
     }
     int sp = sl;
     for (; sp + 12 < ns; sp += 16) {   // four slabs per round: the loads first (one at a time this loop is 8-11 dependent round trips), the adds in slab order
@@ -721,6 +1015,15 @@ size_t wgrad_work_bytes(int D, int njobs) {
   return size_t(kMaxTiles) * (TB * TB + TB) * sizeof(float);
 }
 
+static int64_t knob_rows(const char* name, int64_t dflt) {   // experiment builds read launch-shape knobs from the environment
+#ifdef BSMS_EXPERIMENTS
+  const char* e = getenv(name);
+  return e ? atoll(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
 static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work, hipStream_t s, bool bf, bool h2) {
   BSMS_REQUIRE(njobs >= 0 && njobs <= kMaxWgradJobs, BSMS_E_INVALID_ARG, "wgrad: %d jobs (max %d)", njobs, kMaxWgradJobs);
   BSMS_REQUIRE(D % 4 == 0 && D <= 256, BSMS_E_UNSUPPORTED, "wgrad: D=%d", D);
@@ -728,10 +1031,21 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
   WgradTable tab{};
   tab.njobs = njobs;
   tab.D = D;
-  tab.nblk = (int)ceil_div(D, TB);
-  const int blocks = tab.nblk * tab.nblk;
   int64_t total_rows = 0;
   for (int j = 0; j < njobs; ++j) total_rows += jobs[j].R;
+  tab.nblk = (int)ceil_div(D, TB);
+#ifdef BSMS_EXPERIMENTS
+  static const bool wide_on = [] { const char* e = getenv("BSMS_WGRAD_WIDE"); return !e || atoi(e) != 0; }();   // same-box A/B against the 128 x 128 blocks
+#else
+  constexpr bool wide_on = true;
+#endif
+  static const int64_t wide_min_rows = knob_rows("BSMS_WGRAD_WIDE_MIN", 262144);
+  // D = 256: 128 x 256 tiles, A read once (k_wgrad_wide) -- for launches of edge-level size; short launches keep the 128 x 128 blocks
+  const bool bf64 = bf && [] { const char* e = getenv("BSMS_WGRAD_BF64"); return !e || atoi(e) != 0; }();
+  const bool wide = wide_on && (bf ? bf64 : h2) && D == 2 * TB && !g_wgrad_timing && total_rows >= wide_min_rows;
+  tab.wide = wide ? 1 : 0;
+  const int blocks = wide ? tab.nblk : tab.nblk * tab.nblk;
+  const int tile_units = wide ? 2 : 1;   // partial tiles of 128 x 128 floats a workgroup writes
   // Slab length: aim for ~128 workgroups over all jobs = half the CUs (one workgroup per CU is resident).  Measured
   // (same-box A/B, steps/s of the training step): 64 -> 110.7, 96 -> 125.5, 128 -> 131.0, 160 -> 124.8, 192 -> 126.4,
   // 256 -> 130.5, 512 -> 128.0, 768 -> 126.5: long slabs amortise the pipeline fill and the partial-block traffic, a
@@ -748,7 +1062,7 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
   for (;;) {
     int64_t tiles = 0;
     for (int j = 0; j < njobs; ++j) tiles += std::max<int64_t>(1, ceil_div(jobs[j].R, rows_per)) * blocks;
-    if (tiles <= kMaxTiles) break;
+    if (tiles * tile_units <= kMaxTiles) break;
     rows_per *= 2;
   }
   int first = 0;
@@ -769,12 +1083,24 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
   static DynLdsAttr attr_t_dev;
   const hipError_t attr_t = attr_t_dev.ensure(reinterpret_cast<const void*>(&k_wgrad<true>), (int)lds);
   BSMS_REQUIRE(attr == hipSuccess && attr_t == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS", lds);
-  if (h2) {
+  if (wide && bf) {
+    const size_t lds_bw = size_t(2) * BUF2_W * sizeof(short);   // 104 KB
+    static DynLdsAttr attr_bw_dev;
+    const hipError_t attr_bw = attr_bw_dev.ensure(reinterpret_cast<const void*>(&k_wgrad_bf64_wide), (int)lds_bw);
+    BSMS_REQUIRE(attr_bw == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (bf16 build, 128 x 256 tiles)", lds_bw);
+    hipLaunchKernelGGL(k_wgrad_bf64_wide, dim3(first), dim3(WG_THREADS), lds_bw, s, tab);
+  } else if (wide) {
+    const size_t lds_w = size_t(2) * BUF_W * sizeof(short);   // 104 KB
+    static DynLdsAttr attr_w_dev;
+    const hipError_t attr_w = attr_w_dev.ensure(reinterpret_cast<const void*>(&k_wgrad_wide), (int)lds_w);
+    BSMS_REQUIRE(attr_w == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (128 x 256 tiles)", lds_w);
+    hipLaunchKernelGGL(k_wgrad_wide, dim3(first), dim3(WG_THREADS), lds_w, s, tab);
+  } else if (h2) {
     static DynLdsAttr attr_h_dev;
   const hipError_t attr_h = attr_h_dev.ensure(reinterpret_cast<const void*>(&k_wgrad<false, false, true>), (int)lds);
     BSMS_REQUIRE(attr_h == hipSuccess, BSMS_E_HIP, "wgrad: cannot reserve %zu bytes of LDS (fp16 x 2 build)", lds);
     hipLaunchKernelGGL((k_wgrad<false, false, true>), dim3(first), dim3(WG_THREADS), lds, s, tab);
-  } else if (bf && [] { const char* e = getenv("BSMS_WGRAD_BF64"); return !e || atoi(e) != 0; }()) {
+  } else if (bf64) {
     const size_t lds_b = size_t(2) * 2 * PLANE2 * sizeof(short);   // 72 KB: 2 x [G|A][64 rows][288 B]
     static DynLdsAttr attr_b64_dev;
   const hipError_t attr_b64 = attr_b64_dev.ensure(reinterpret_cast<const void*>(&k_wgrad_bf64), (int)lds_b);

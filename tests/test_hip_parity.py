@@ -431,6 +431,52 @@ def test_gmp_other_widths(eng, D, p, H):
         assert rel_err(pm.grad.cpu(), pr.grad) < BWD_TOL, k
 
 
+def test_gmp_d256_wide_weight_gradient_tiles(eng):
+    """D = 256 with enough rows (3 x 90 000 edge rows >= 262 144) for the weight gradients to take the 128 x 256 tiles of
+    k_wgrad_wide (round 6: A read once per slab instead of twice).  7e7 ReLU inputs: dozens lie within 1e-8 of zero, so any two
+    fp32 summation orders disagree on some masks and every edge-MLP gradient moves by ~2e-3 of its scale (measured; see
+    test_gmp_launch_shapes).  Criterion = the three-way one of test_hip_fullsize.py: the engine's distance to an fp64 run is at
+    most 1.5 x the fp32 oracle's (the larger of its all-threads and one-thread runs), worst tensor and median; a wrong tile
+    would corrupt whole 16 x 16 blocks of dW (error ~1).  Forward three-way; input gradient within 1e-5 on all but a few rows."""
+    D, p, H, n, e, B = 256, 3, 3, 6000, 45000, 2
+    g = random_graph(n, e, 11)
+    torch.manual_seed(23)
+    ref = ro.GMP(D, H, p)
+    x, pos, r = torch.randn(B, n, D), torch.rand(B, n, p), torch.randn(B, n, D)
+    def run(dt):
+        m = ro.GMP(D, H, p).to(dt)
+        m.load_state_dict({k: v.to(dt) for k, v in ref.state_dict().items()})
+        xx = x.to(dt).clone().requires_grad_(True)
+        y = m(xx, g, pos.to(dt))
+        (y * r.to(dt)).sum().backward()
+        return y.detach(), xx.grad, {k: q.grad for k, q in m.named_parameters()}
+    y64, gx64, gw64 = run(torch.float64)
+    y32, _, gw32 = run(torch.float32)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        _, _, gw32_one = run(torch.float32)
+    finally:
+        torch.set_num_threads(nthreads)
+    mine = load_sd(eng.GMP(D, H, p), ref.state_dict())
+    xd = dev(x).requires_grad_(True)
+    yd = mine(xd, dev(g), dev(pos))
+    (yd * dev(r)).sum().backward()
+    err = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+    assert err(yd.detach(), y64) <= 3.0 * err(y32, y64) + 2e-6
+    row_err = (xd.grad.double().cpu() - gx64).abs().amax(-1).reshape(-1) / float(gx64.abs().max())
+    outliers = int((row_err > 1e-5).sum())
+    assert outliers <= max(4, B * n // 500), (outliers, float(row_err.max()))
+    errs = {k: err(q.grad, gw64[k]) for k, q in mine.named_parameters()}
+    med = lambda d: sorted(d.values())[len(d) // 2]
+    ref_n = {k: err(gw32[k], gw64[k]) for k in errs}
+    ref_1 = {k: err(gw32_one[k], gw64[k]) for k in errs}
+    print(f"\n[d256 wide] dW vs fp64: gpu worst {max(errs.values()):.2e} median {med(errs):.2e} | cpu32 all threads worst {max(ref_n.values()):.2e} "
+          f"median {med(ref_n):.2e} | cpu32 one thread worst {max(ref_1.values()):.2e} median {med(ref_1):.2e}")
+    assert max(errs.values()) <= 1.5 * max(max(ref_n.values()), max(ref_1.values())) + 1e-6, errs
+    assert med(errs) <= 1.5 * max(med(ref_n), med(ref_1)) + 1e-6, errs
+
+
 def test_split_products_are_fp32_accurate(eng):
     """The matrix cores multiply fp16 x 2 pieces of power-of-two-scaled fp32 operands, three partial products (chain.h;
     profiles/census/f16split.hip).  Against an fp64 computation the engine must be at least as accurate as plain fp32
