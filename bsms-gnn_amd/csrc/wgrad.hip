@@ -391,14 +391,31 @@ __device__ __forceinline__ bf16x8 column_fragment_w(const short* plane, int col0
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// Tile of a wide launch -> (slab, block of G columns).  The two workgroups of a slab read the same rows of A: they are placed EIGHT
+// workgroup indices apart, i.e. on the same XCD (workgroups go round-robin over the 8 XCDs) and in the same dispatch round, so that the
+// second read of an A chunk is served by that XCD's L2 instead of HBM.  Whole groups of 8 slabs; the last slabs pair up as neighbours.
+__device__ __forceinline__ void wide_tile(int local, int nsplit, int& split, int& bi) {
+  const int full = (nsplit >> 3) << 3;
+  if (local < 2 * full) {
+    const int r = local & 15;
+    bi = r >> 3;
+    split = ((local >> 4) << 3) + (r & 7);
+  } else {
+    const int l2 = local - 2 * full;
+    split = full + (l2 >> 1);
+    bi = l2 & 1;
+  }
+}
+
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_wide(WgradTable tab) {
   extern __shared__ __attribute__((aligned(16))) short planes[];  // [2 buffers][G h | G l | A h | A l]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int j = 0;
   while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
   const WgradJob job = tab.job[j];
-  const int local = blockIdx.x - tab.first_tile[j];
-  const int bi = local % tab.nblk, split = local / tab.nblk;
+  int split, bi;
+  wide_tile(blockIdx.x - tab.first_tile[j], tab.nsplit[j], split, bi);
+  const int64_t tile = tab.first_tile[j] + split * 2 + bi;   // where k_wgrad_reduce looks for this block's partial sums
   const int64_t r0 = int64_t(split) * tab.rows_per_wg[j];
   const int64_t r1 = min(job.R, r0 + tab.rows_per_wg[j]);
   const int nchunk = int((r1 - r0 + RC - 1) / RC);
@@ -474,9 +491,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_wide(WgradTable tab) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (nchunk == 0) {   // cannot happen for a launched slab; keeps the unconditional loads in range
-    float* part0 = tab.partials + int64_t(blockIdx.x) * TILE;
+    float* part0 = tab.partials + tile * TILE;
     for (int o = tid; o < TILE; o += WG_THREADS) part0[o] = 0.f;
-    if (want_db && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = 0.f;
+    if (want_db && tid < TB) tab.colsums[tile * TB + tid] = 0.f;
     return;
   }
 #pragma unroll
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_wide(WgradTable tab) {
   }
   // D[row = 4 q + r][col = c] of block (a, b) = dW[n0 + 32 wr + 16 a + 4 q + r][64 wc + 16 b + c]
   const int q = lane >> 4, cc = lane & 15;
-  float* part = tab.partials + int64_t(blockIdx.x) * TILE;
+  float* part = tab.partials + tile * TILE;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -534,7 +551,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_wide(WgradTable tab) {
     if (tid < 32) {
       f32x4 v = red[tid];
       for (int l = 1; l < 32; ++l) v += red[l * 32 + tid];
-      *reinterpret_cast<f32x4*>(tab.colsums + int64_t(blockIdx.x) * TB + tid * 4) = v;
+      *reinterpret_cast<f32x4*>(tab.colsums + tile * TB + tid * 4) = v;
     }
   }
 }
@@ -675,18 +692,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_bf64_wide(WgradTable tab) 
   int j = 0;
   while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
   const WgradJob job = tab.job[j];
-  const int local = blockIdx.x - tab.first_tile[j];
-  const int bi = local % tab.nblk, split = local / tab.nblk;
+  int split, bi;
+  wide_tile(blockIdx.x - tab.first_tile[j], tab.nsplit[j], split, bi);
+  const int64_t tile = tab.first_tile[j] + split * 2 + bi;
   const int64_t r0 = int64_t(split) * tab.rows_per_wg[j];
   const int64_t r1 = min(job.R, r0 + tab.rows_per_wg[j]);
   const int nchunk = int((r1 - r0 + RC2 - 1) / RC2);
   const int n0 = bi * TB;
   constexpr int TILE = TB * 2 * TB;
-  float* part = tab.partials + int64_t(blockIdx.x) * TILE;
+  float* part = tab.partials + tile * TILE;
   const bool want_db = job.db != nullptr;
   if (nchunk == 0) {   // cannot happen for a launched slab
     for (int o = tid; o < TILE; o += WG_THREADS) part[o] = 0.f;
-    if (want_db && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = 0.f;
+    if (want_db && tid < TB) tab.colsums[tile * TB + tid] = 0.f;
     return;
   }
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -777,7 +795,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_bf64_wide(WgradTable tab) 
     if (tid < TB) {
       float v = red[tid];
       for (int l = 1; l < 64; ++l) v += red[l * TB + tid];
-      tab.colsums[int64_t(blockIdx.x) * TB + tid] = v;
+      tab.colsums[tile * TB + tid] = v;
     }
   }
 }
