@@ -7,7 +7,7 @@ out=gpurun_out/step_pmc
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   tag=$(echo $c | cut -d' ' -f1)
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$tag -o x -- python bench.py --dtype ${DTYPE:-f32} --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-other-lines > $out/$tag.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$tag -o x -- python bench.py ${WL} --dtype ${DTYPE:-f32} --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-other-lines > $out/$tag.log 2>&1
 done
 python - <<'PY' | tee gpurun_out/step_pmc/summary.txt
 import csv, glob, re, collections
