@@ -117,6 +117,38 @@ __device__ __forceinline__ f32x4 mma_h(const bf16x8& a, const bf16x8& b, f32x4 c
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Tile of a launch -> (slab, block row, block column).  At D = 256 (nblk = 2) the four workgroups of a slab read the same rows of G
+// and A (two of them each half): they are placed EIGHT workgroup indices apart -- same XCD (workgroups go round-robin over the 8
+// XCDs), same dispatch round -- so that three of the four reads of a chunk are served by that XCD's L2 (round 6; measured on the
+// 128 x 256 tiles of k_wgrad_wide: 1.04 x the algorithmic bytes from HBM instead of 2 x).  nblk = 1: the identity.  `tile` is where
+// k_wgrad_reduce looks for the block's partial sums (slab-major, as before).
+struct TileRef { int split, bi, bj; int64_t tile; };
+__device__ __forceinline__ TileRef tile_of(const WgradTable& tab, int j, int block) {
+  const int local = block - tab.first_tile[j];
+  TileRef t;
+  if (tab.nblk == 2) {
+    const int full = (tab.nsplit[j] >> 3) << 3;
+    int blk;
+    if (local < 4 * full) {
+      const int r = local & 31;
+      blk = r >> 3;
+      t.split = ((local >> 5) << 3) + (r & 7);
+    } else {
+      const int l2 = local - 4 * full;
+      t.split = full + (l2 >> 2);
+      blk = l2 & 3;
+    }
+    t.bi = blk >> 1;
+    t.bj = blk & 1;
+  } else {
+    t.bj = local % tab.nblk;
+    t.bi = (local / tab.nblk) % tab.nblk;
+    t.split = local / (tab.nblk * tab.nblk);
+  }
+  t.tile = tab.first_tile[j] + (int64_t(t.split) * tab.nblk + t.bi) * tab.nblk + t.bj;
+  return t;
+}
+
 constexpr int WG_THREADS = 1024;  // 16 waves = 4 per SIMD, one workgroup per CU
 constexpr int NPF = 3;            // chunks in flight in registers beyond the one being staged
 static_assert(NPF == 3, "the step schedule in k_wgrad is written out for three register sets");
@@ -131,8 +163,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   int j = 0;
   while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
   const WgradJob job = tab.job[j];
-  const int local = blockIdx.x - tab.first_tile[j];
-  const int bj = local % tab.nblk, bi = (local / tab.nblk) % tab.nblk, split = local / (tab.nblk * tab.nblk);
+  const TileRef tr = tile_of(tab, j, blockIdx.x);
+  const int bj = tr.bj, bi = tr.bi, split = tr.split;
   const int D = tab.D;
   const int64_t r0 = int64_t(split) * tab.rows_per_wg[j];
   const int64_t r1 = min(job.R, r0 + tab.rows_per_wg[j]);
@@ -241,9 +273,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
   // chunk c is staged from register set c % NPF into LDS buffer c & 1 one iteration before its MFMAs; one barrier
   // per chunk orders "buffer written" and "buffer free" at once
   if (nchunk == 0) {   // cannot happen for a launched slab; keeps the unconditional loads in range
-    float* part0 = tab.partials + int64_t(blockIdx.x) * (TB * TB);
+    float* part0 = tab.partials + tr.tile * (TB * TB);
     for (int o = tid; o < TB * TB; o += WG_THREADS) part0[o] = 0.f;
-    if (want_db && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = 0.f;
+    if (want_db && tid < TB) tab.colsums[tr.tile * TB + tid] = 0.f;
     return;
   }
 #pragma unroll
@@ -349,7 +381,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
 
   // D[row = 4 q + r][col = c] of block (a, b) = dW[32 wr + 16 a + 4 q + r][32 wc + 16 b + c]
   const int q = lane >> 4, cc = lane & 15;
-  float* part = tab.partials + int64_t(blockIdx.x) * (TB * TB);
+  float* part = tab.partials + tr.tile * (TB * TB);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -364,7 +396,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradTable tab) {
     if (tid < 32) {
       f32x4 v = red[tid];
       for (int l = 1; l < 32; ++l) v += red[l * 32 + tid];
-      *reinterpret_cast<f32x4*>(tab.colsums + int64_t(blockIdx.x) * TB + tid * 4) = v;
+      *reinterpret_cast<f32x4*>(tab.colsums + tr.tile * TB + tid * 4) = v;
     }
   }
 }
@@ -572,18 +604,18 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_bf64(WgradTable tab) {
   int j = 0;
   while (j + 1 < tab.njobs && int(blockIdx.x) >= tab.first_tile[j + 1]) ++j;
   const WgradJob job = tab.job[j];
-  const int local = blockIdx.x - tab.first_tile[j];
-  const int bj = local % tab.nblk, bi = (local / tab.nblk) % tab.nblk, split = local / (tab.nblk * tab.nblk);
+  const TileRef tr = tile_of(tab, j, blockIdx.x);
+  const int bj = tr.bj, bi = tr.bi, split = tr.split;
   const int D = tab.D;
   const int64_t r0 = int64_t(split) * tab.rows_per_wg[j];
   const int64_t r1 = min(job.R, r0 + tab.rows_per_wg[j]);
   const int nchunk = int((r1 - r0 + RC2 - 1) / RC2);
   const int n0 = bi * TB, k0 = bj * TB;
-  float* part = tab.partials + int64_t(blockIdx.x) * (TB * TB);
+  float* part = tab.partials + tr.tile * (TB * TB);
   const bool want_db = job.db && bj == 0;
   if (nchunk == 0) {   // cannot happen for a launched slab
     for (int o = tid; o < TB * TB; o += WG_THREADS) part[o] = 0.f;
-    if (want_db && tid < TB) tab.colsums[int64_t(blockIdx.x) * TB + tid] = 0.f;
+    if (want_db && tid < TB) tab.colsums[tr.tile * TB + tid] = 0.f;
     return;
   }
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -676,7 +708,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_bf64(WgradTable tab) {
     if (tid < TB) {
       float v = red[tid];
       for (int l = 1; l < 64; ++l) v += red[l * TB + tid];
-      tab.colsums[int64_t(blockIdx.x) * TB + tid] = v;
+      tab.colsums[tr.tile * TB + tid] = v;
     }
   }
 }
