@@ -19,6 +19,10 @@
 // k_wgrad_reduce (deterministic; no float atomics).  Several layers' gradients are batched into one launch so the
 // small coarse levels still fill the chip.  The bias gradient (column sums of G) is accumulated in fp32 by the
 // staging threads.
+// D = 256 (round 6): four 128 x 128 blocks per slab would read -- and split -- every row of G and A twice.  Launches of edge-level
+// size take k_wgrad_wide / k_wgrad_bf64_wide (a workgroup owns 128 x 256 of dW: A staged once), and in every tiling the workgroups
+// of one slab are placed on the same XCD (tile_of / wide_tile) so that the remaining duplicate reads are L2 hits: 1.04 x the
+// algorithmic bytes from HBM (profiles/r06_step_pmc_surface.txt).
 #include "chain.h"
 #include <cstdlib>
 #include <type_traits>
