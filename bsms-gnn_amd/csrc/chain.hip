@@ -1806,10 +1806,24 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
       return BSMS_OK;
     }
   }
-  const int cw = (IN == IN_EDGE) ? bf_edge_waves<NB>(a.R) : chain_compute_waves<NB>(a.R);
+  int cw = (IN == IN_EDGE) ? bf_edge_waves<NB>(a.R) : chain_compute_waves<NB>(a.R);
   a.ntiles = (int)ceil_div(a.R, 16 * cw);
-  if (a.bf16) pick_stream<NB, 1>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
-  else pick_stream<NB>(a.ntiles, cw, chain_loader_waves(), a.nload, a.nring);
+  // One Linear over [x, x2] added into y (the input gradient through the two edge projections, gmp.hip): three more dependent row
+  // loads per tile than a plain chain and only two packs of MFMAs to hide them under.  The single-round build keeps x2 in registers
+  // (one round trip instead of three) -- so this launch always takes it, one 7-wave workgroup per CU striding over the tiles
+  // (round 6, profiles/r06_rows2.txt).
+  bool rows2_lone = false;
+  if constexpr (NB == 8 && IN == IN_ROWS2 && OUT == OUT_PLAIN) {
+    static const int on = knob("BSMS_ROWS2_LONE", 1);
+    if (on && !a.bf16 && a.nstage == 1 && a.ntiles > device_cus()) {
+      rows2_lone = true;
+      cw = 7;
+      a.ntiles = (int)ceil_div(a.R, 16 * cw);
+    }
+  }
+  const int64_t stream_tiles = rows2_lone ? std::min<int64_t>(a.ntiles, device_cus()) : a.ntiles;   // ring depth / loaders of a one-workgroup-per-CU launch
+  if (a.bf16) pick_stream<NB, 1>(stream_tiles, cw, chain_loader_waves(), a.nload, a.nring);
+  else pick_stream<NB>(stream_tiles, cw, chain_loader_waves(), a.nload, a.nring);
   const dim3 threads((cw + a.nload) * 64);
   // the bf16 precision's chunks are one plane: its ring may be deeper than the fp32 one at the same D, size it as what it is
   const size_t lds = a.bf16 ? Ring<NB, 1>::lds_bytes(a.nring) : Ring<NB>::lds_bytes(a.nring);
@@ -1845,11 +1859,12 @@ int launch_fwd_t(const ChainFwdArgs& a0, hipStream_t s) {
   }
   BSMS_REQUIRE(launched || !a.bf16, BSMS_E_UNSUPPORTED, "chain_fwd: bf16 precision is built for the edge and node MLPs at D = 128 / 256 only");
   if constexpr (NB >= 8) {   // one round of workgroups = a single wave per SIMD: the variant that prefetches its fragments (mfma_stage)
-    if (!launched && a.ntiles <= device_cus()) {
+    if (!launched && (a.ntiles <= device_cus() || rows2_lone)) {
       static DynLdsAttr lattr_dev;
   const hipError_t lattr = lattr_dev.ensure(reinterpret_cast<const void*>(&k_chain_fwd<NB, IN, OUT, false, false, true>), (int)Ring<NB>::lds_bytes(max_ring<NB>()));
       BSMS_REQUIRE(lattr == hipSuccess, BSMS_E_HIP, "chain_fwd: cannot reserve LDS (single-round build)");
-      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, false, true>), dim3(persistent_grid<NB>(a.ntiles)), threads, lds, s, a);
+      const unsigned grid = rows2_lone ? (unsigned)std::min<int64_t>(a.ntiles, device_cus()) : persistent_grid<NB>(a.ntiles);
+      hipLaunchKernelGGL((k_chain_fwd<NB, IN, OUT, false, false, true>), dim3(grid), threads, lds, s, a);
       launched = true;
     }
   }

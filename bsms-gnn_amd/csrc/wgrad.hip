@@ -1106,7 +1106,9 @@ static int launch_wgrad_same(int D, const WgradJob* jobs, int njobs, void* work,
   // grid that spills into a second, nearly empty round loses, and half the chip is left to the kernels that run
   // concurrently on the caller's stream.  Slabs are multiples of 6 chunks, at least 128 rows.
 #ifdef BSMS_EXPERIMENTS
-  static const int target_wgs = [] { const char* e = getenv("BSMS_WGRAD_WGS"); return e ? atoi(e) : 128; }();
+  static const int target_h2 = [] { const char* e = getenv("BSMS_WGRAD_WGS"); return e ? atoi(e) : 128; }();
+  static const int target_bf3 = [] { const char* e = getenv("BSMS_WGRAD_WGS_BF3"); return e ? atoi(e) : 128; }();   // the range-free jobs (second side lane)
+  const int target_wgs = (h2 || bf) ? target_h2 : target_bf3;
 #else
   constexpr int target_wgs = 128;
 #endif
